@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libdvsg_amd.so (gfx950 only) in-tree.  Usage: ./build.sh [extra hipcc flags]
+set -euo pipefail
+cd "$(dirname "$0")"
+SRC=coupe/dvsg_amd/csrc
+OUT=coupe/dvsg_amd/libdvsg_amd.so
+OBJ=build/obj
+mkdir -p "$OBJ"
+COMMON="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $*"
+pids=()
+# warps: separately rounded float32 ops like the reference graph (see warp_kernels.hip)
+hipcc $COMMON -ffp-contract=off -c $SRC/warp_kernels.hip -o $OBJ/warp_kernels.o & pids+=($!)
+hipcc $COMMON -c $SRC/cnn_kernels.hip -o $OBJ/cnn_kernels.o & pids+=($!)
+hipcc $COMMON -c $SRC/locnet.hip -o $OBJ/locnet.o & pids+=($!)
+hipcc $COMMON -x hip -c $SRC/api_common.cpp -o $OBJ/api_common.o & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/warp_kernels.o $OBJ/cnn_kernels.o $OBJ/locnet.o $OBJ/api_common.o
+echo "built $OUT"

@@ -1,0 +1,79 @@
+"""ctypes binding of libdvsg_amd.so (include/dvsg_amd.h).
+
+There is no fallback of any kind: if the shared library is missing, or was built for
+another ABI version, importing a compute entry point raises.  Tensor plumbing (device
+memory, streams) is PyTorch-ROCm; every compute call goes through the C ABI with raw
+device pointers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvsg_amd.so")
+ABI_VERSION = 1
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+
+# name -> argtypes; every function returns int status except the three string/version queries.
+SIGNATURES = {
+    "dvsg_tps_solve_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "dvsg_tps_warp_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dvsg_flow_warp_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "dvsg_stn_sample_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "dvsg_grid_affine_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dvsg_grid_projective_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dvsg_elastic_constants_f32": [_i, _vp, _vp],
+    "dvsg_grid_elastic_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dvsg_scale_rgb_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "dvsg_locnet_create": [_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_vp),
+                           ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(_vp)],
+    "dvsg_locnet_destroy": [_vp],
+    "dvsg_locnet_in_channels": [_vp],
+    "dvsg_locnet_workspace_bytes": [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t)],
+    "dvsg_locnet_forward_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_locnet_forward_tap_f32": [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t,
+                                    ctypes.POINTER(_i), _vp, ctypes.c_size_t, _vp],
+    "dvsg_stabilize_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+}
+QUERIES = ("dvsg_abi_version", "dvsg_last_error_string", "dvsg_target_arch")
+
+_lib = None
+
+
+class DvsgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises if it is absent or mismatched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DvsgError(
+            "libdvsg_amd.so not found at %s: build it with ./build.sh (hipcc --offload-arch=gfx950). "
+            "coupe.dvsg_amd has no CPU or PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dvsg_abi_version.restype = ctypes.c_int
+    lib.dvsg_last_error_string.restype = ctypes.c_char_p
+    lib.dvsg_target_arch.restype = ctypes.c_char_p
+    if lib.dvsg_abi_version() != ABI_VERSION:
+        raise DvsgError("libdvsg_amd.so ABI %d != expected %d" % (lib.dvsg_abi_version(), ABI_VERSION))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().dvsg_last_error_string().decode("utf-8", "replace")
+        raise DvsgError("%s failed (status %d): %s" % (what, status, msg))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,50 @@
+// Launch interface of the localizationNet kernels (cnn_kernels.hip), used by locnet.hip.
+#pragma once
+#include "common.h"
+
+namespace dvsg {
+
+// Implicit-GEMM convolution (1x1 or 3x3, NHWC float32, C_in % 32 == 0, C_out % 64 == 0):
+//   y[m, n] = act( sum_k A[m, k] * wt[n, k] + bias[n] (+ res[...]) )
+// with m = (b, ho, wo), k = (kh, kw, c).  wt is [C_out][K] (K contiguous, BN scale folded in).
+struct ConvGemm {
+  const float *x;     // [B,H,W,Cin]
+  const float *wt;    // [Cout][ksize*ksize*Cin]
+  const float *bias;  // [Cout]
+  const float *res;   // optional residual [B,res_H,res_W,Cout], sampled at (ho*res_stride, wo*res_stride)
+  float *y;           // [B,Ho,Wo,Cout]
+  int B, H, W, Cin, Ho, Wo, Cout;
+  int ksize, stride, pad;
+  int res_H, res_W, res_stride;
+  int relu;
+};
+int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
+
+// conv1: 7x7 stride 2, explicit pad 3, C_in = 21 -> 64, with scale_RGB fused into the LDS
+// load stage (networks.py:6-16 + slim conv2d_same root).  wt1 is [7][64][kConv1Ld]:
+// per kernel row kh, per output channel, the 7*21 (kw, c) taps in memory order of the
+// input row (+ zero padding), BN scale folded, channel-group reversal folded.
+constexpr int kConv1Cin = 21;
+constexpr int kConv1K = 7 * kConv1Cin;   // 147 taps per kernel row
+constexpr int kConv1Kpad = 148;          // rounded to the 4-k MFMA step
+constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conflict-free ds_read_b64)
+int launch_conv1(const float *x, const float *wt1, const float *bias, float *y, int B, int H, int W,
+                 int Ho, int Wo, hipStream_t s);
+
+// 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 4 == 0.
+int launch_maxpool(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
+                   int pad_left, hipStream_t s);
+
+// Global average pool as partial sums: part[b][s][c] = sum over the s-th slice of HW.
+constexpr int kPoolSplits = 8;
+int launch_avgpool_partial(const float *x, float *part, int B, int HW, int C, hipStream_t s);
+
+// Dense layer on split partial sums (see cnn_kernels.hip).
+constexpr int kDenseSplits = 8;
+int launch_dense(const float *xin, int s_in, const float *bias_in, float scale_in, int lrelu_in,
+                 const float *W, float *out_part, int B, int K, int N, hipStream_t s);
+// out[b][n] = scale * sum_s part[b][s][n] + bias[n] (bias may be NULL)
+int launch_dense_finalize(const float *part, int s_in, float scale, const float *bias, float *out, int B,
+                          int N, hipStream_t s);
+
+}  // namespace dvsg

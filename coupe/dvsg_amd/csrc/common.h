@@ -1,0 +1,47 @@
+// Shared host-side helpers for libdvsg_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../../include/dvsg_amd.h"
+
+namespace dvsg {
+
+// Thread-local last-error text returned by dvsg_last_error_string().
+char *error_buffer();
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Check the launch itself (invalid configuration etc.); execution errors surface at the
+// caller's next synchronisation, as for any stream-ordered API.
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DVSG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return DVSG_OK;
+}
+
+#define DVSG_REQUIRE(cond, ...)                                  \
+  do {                                                           \
+    if (!(cond)) return ::dvsg::fail(DVSG_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define DVSG_HIP(call)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return ::dvsg::fail(DVSG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));    \
+  } while (0)
+
+// warp_kernels.hip internals shared with locnet.hip (coord_bstride in floats; 0 = broadcast)
+int tps_solve_impl(const float *coord, long coord_bstride, const float *rhs, int rhs_is_vector, int B,
+                   int P, float *T, void *stream);
+int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const float *T, int B, int H,
+                  int W, int C, int P, int out_h, int out_w, float *out, float *x_s, float *y_s,
+                  void *stream);
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace dvsg

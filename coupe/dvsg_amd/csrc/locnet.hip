@@ -1,0 +1,423 @@
+// Host side of localizationNet (networks.py:30-46) and of the fused evaluation graph
+// (model.py:98-123): checkpoint ingestion (BatchNorm folding, weight re-layout for the MFMA
+// fragment scheme of cnn_kernels.hip), workspace planning and the launch sequence.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "cnn_kernels.h"
+
+namespace dvsg {
+namespace {
+
+constexpr float kBnEps = 1e-5f;  // slim resnet_arg_scope batch_norm_epsilon
+const char *kPrefix = "stabNet/localizationNet/";  // model.py:114-117
+
+struct HostArray {
+  const float *data;
+  int nd;
+  int64_t dims[4];
+  size_t size() const {
+    size_t n = 1;
+    for (int i = 0; i < nd; ++i) n *= (size_t)dims[i];
+    return n;
+  }
+};
+
+struct ConvLayer {
+  int ksize, cin, cout, stride;
+  bool relu;
+  float *wt = nullptr;    // device, [cout][k*k*cin] (conv1: [7][64][kConv1Ld])
+  float *bias = nullptr;  // device, [cout]
+};
+
+struct Unit {
+  int base, depth, stride;
+  bool has_shortcut;
+  ConvLayer shortcut, c1, c2, c3;
+};
+
+struct BlockSpec {
+  const char *name;
+  int base, units, last_stride;
+};
+const BlockSpec kBlocks[4] = {{"block1", 64, 3, 2}, {"block2", 128, 4, 2}, {"block3", 256, 6, 2}, {"block4", 512, 3, 1}};
+const int kDenseDims[4][2] = {{2048, 2048}, {2048, 1024}, {1024, 512}, {512, 50}};
+
+}  // namespace
+}  // namespace dvsg
+
+using namespace dvsg;
+
+struct dvsg_locnet {
+  int c_in = 0;
+  ConvLayer conv1;
+  std::vector<Unit> units;
+  float *dense_w[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *dense_b[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *v_src = nullptr;  // [25,2] model.py:105-110
+  std::vector<void *> allocs;
+};
+
+namespace dvsg {
+namespace {
+
+typedef std::map<std::string, HostArray> ArrayMap;
+
+int find(const ArrayMap &m, const std::string &name, std::initializer_list<int64_t> shape, const HostArray **out) {
+  auto it = m.find(name);
+  if (it == m.end()) return fail(DVSG_ERR_WEIGHTS, "checkpoint array missing: %s", name.c_str());
+  const HostArray &a = it->second;
+  bool ok = a.nd == (int)shape.size();
+  int i = 0;
+  for (int64_t s : shape) {
+    if (ok && a.dims[i] != s) ok = false;
+    ++i;
+  }
+  if (!ok) {
+    std::string want, got;
+    for (int64_t s : shape) want += std::to_string(s) + ",";
+    for (int j = 0; j < a.nd; ++j) got += std::to_string(a.dims[j]) + ",";
+    return fail(DVSG_ERR_WEIGHTS, "checkpoint array %s has shape [%s] expected [%s]", name.c_str(), got.c_str(),
+                want.c_str());
+  }
+  *out = &a;
+  return DVSG_OK;
+}
+
+int upload(dvsg_locnet *net, const std::vector<float> &h, float **dev) {
+  void *p = nullptr;
+  DVSG_HIP(hipMalloc(&p, h.size() * sizeof(float)));
+  net->allocs.push_back(p);
+  DVSG_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dev = static_cast<float *>(p);
+  return DVSG_OK;
+}
+
+// BatchNorm inference folded to y = conv(x, w * scale) + shift.
+int bn_fold(const ArrayMap &m, const std::string &scope, int c, std::vector<float> *scale, std::vector<float> *shift) {
+  const HostArray *g, *b, *mu, *var;
+  if (int rc = find(m, scope + "/BatchNorm/gamma", {c}, &g)) return rc;
+  if (int rc = find(m, scope + "/BatchNorm/beta", {c}, &b)) return rc;
+  if (int rc = find(m, scope + "/BatchNorm/moving_mean", {c}, &mu)) return rc;
+  if (int rc = find(m, scope + "/BatchNorm/moving_variance", {c}, &var)) return rc;
+  scale->resize(c);
+  shift->resize(c);
+  for (int i = 0; i < c; ++i) {
+    const float inv = g->data[i] / std::sqrt(var->data[i] + kBnEps);
+    (*scale)[i] = inv;
+    (*shift)[i] = b->data[i] - mu->data[i] * inv;
+  }
+  return DVSG_OK;
+}
+
+// Generic conv: HWIO -> [cout][kh][kw][cin] with the BN scale folded in.
+int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, ConvLayer *L) {
+  const HostArray *w;
+  if (int rc = find(m, scope + "/weights", {L->ksize, L->ksize, L->cin, L->cout}, &w)) return rc;
+  std::vector<float> scale, shift;
+  if (int rc = bn_fold(m, scope, L->cout, &scale, &shift)) return rc;
+  const int K = L->ksize * L->ksize * L->cin;
+  std::vector<float> wt((size_t)L->cout * K);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < L->cout; ++n) wt[(size_t)n * K + k] = w->data[(size_t)k * L->cout + n] * scale[n];
+  if (int rc = upload(net, wt, &L->wt)) return rc;
+  return upload(net, shift, &L->bias);
+}
+
+// conv1: [7][64][kConv1Ld]; within a kernel row the taps run (kw, raw channel c) in input
+// memory order.  scale_RGB's group reversal (networks.py:10-14) is folded here: raw channel
+// c multiplies the weight of scaled-tensor channel (2 - c/G) * G + c % G.
+int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, ConvLayer *L) {
+  const HostArray *w;
+  if (int rc = find(m, scope + "/weights", {7, 7, L->cin, 64}, &w)) return rc;
+  std::vector<float> scale, shift;
+  if (int rc = bn_fold(m, scope, 64, &scale, &shift)) return rc;
+  const int cin = L->cin, G = cin / 3;
+  std::vector<float> wt((size_t)7 * 64 * kConv1Ld, 0.f);
+  for (int kh = 0; kh < 7; ++kh)
+    for (int kw = 0; kw < 7; ++kw)
+      for (int c = 0; c < cin; ++c) {
+        const int cs = (2 - c / G) * G + c % G;
+        for (int n = 0; n < 64; ++n)
+          wt[((size_t)kh * 64 + n) * kConv1Ld + kw * cin + c] =
+              w->data[(((size_t)kh * 7 + kw) * cin + cs) * 64 + n] * scale[n];
+      }
+  if (int rc = upload(net, wt, &L->wt)) return rc;
+  return upload(net, shift, &L->bias);
+}
+
+struct Dims {
+  int H1, W1, Hp, Wp, pad_top, pad_left;
+};
+
+Dims root_dims(int H, int W) {
+  Dims d;
+  d.H1 = (H - 1) / 2 + 1;  // conv2d_same(7, stride 2): pad 3/3 then VALID
+  d.W1 = (W - 1) / 2 + 1;
+  d.Hp = (d.H1 + 1) / 2;   // max_pool2d 3x3/2 SAME
+  d.Wp = (d.W1 + 1) / 2;
+  const int pth = std::max((d.Hp - 1) * 2 + 3 - d.H1, 0), ptw = std::max((d.Wp - 1) * 2 + 3 - d.W1, 0);
+  d.pad_top = pth / 2;
+  d.pad_left = ptw / 2;
+  return d;
+}
+
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Workspace {
+  float *bufA, *bufB, *bufS, *r1, *r2, *pool_part, *dpart0, *dpart1, *T, *Ft;
+  size_t total;
+};
+
+Workspace plan(char *base, int B, int H, int W) {
+  const Dims d = root_dims(H, W);
+  const size_t big = align256((size_t)B * d.Hp * d.Wp * 256 * sizeof(float));
+  const size_t small = align256((size_t)B * d.Hp * d.Wp * 64 * sizeof(float));
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char *p = base + off;
+    off += align256(bytes);
+    return reinterpret_cast<float *>(p);
+  };
+  w.bufA = take(big);
+  w.bufB = take(big);
+  w.bufS = take(big);
+  w.r1 = take(small);
+  w.r2 = take(small);
+  w.pool_part = take((size_t)kPoolSplits * B * 2048 * sizeof(float));
+  w.dpart0 = take((size_t)kDenseSplits * 16 * 2048 * sizeof(float));
+  w.dpart1 = take((size_t)kDenseSplits * 16 * 2048 * sizeof(float));
+  w.T = take((size_t)B * 2 * 28 * sizeof(float));
+  w.Ft = take((size_t)B * 50 * sizeof(float));
+  w.total = off;
+  return w;
+}
+
+int run_conv(const ConvLayer &L, const float *x, int B, int H, int W, float *y, int Ho, int Wo, const float *res,
+             int res_H, int res_W, int res_stride, bool relu, hipStream_t s) {
+  ConvGemm p;
+  p.x = x; p.wt = L.wt; p.bias = L.bias; p.res = res; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
+  p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
+  p.res_H = res_H; p.res_W = res_W; p.res_stride = res_stride;
+  p.relu = relu;
+  return launch_conv_gemm(p, s);
+}
+
+// Runs the network; stop_stage < 0 runs everything and writes F_t [B,50].
+int forward(const dvsg_locnet *net, const float *patches, int B, int H, int W, float *F_t, int stop_stage,
+            float *act_out, size_t act_out_bytes, int *act_dims, void *workspace, size_t workspace_bytes,
+            hipStream_t s) {
+  DVSG_REQUIRE(net && patches && workspace, "locnet forward: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H >= 1 && W >= 1, "locnet forward: bad shape B=%d H=%d W=%d", B, H, W);
+  DVSG_REQUIRE(((uintptr_t)workspace & 255) == 0, "locnet forward: workspace must be 256-byte aligned");
+  const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
+  if (ws.total > workspace_bytes)
+    return fail(DVSG_ERR_WORKSPACE, "locnet forward: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
+  const Dims d = root_dims(H, W);
+
+  auto tap = [&](int stage, const float *act, int h, int w, int c) -> int {
+    if (stage != stop_stage) return 0;
+    const size_t bytes = (size_t)B * h * w * c * sizeof(float);
+    if (bytes > act_out_bytes) return fail(DVSG_ERR_INVALID_ARG, "tap buffer %zu bytes < %zu", act_out_bytes, bytes);
+    DVSG_HIP(hipMemcpyAsync(act_out, act, bytes, hipMemcpyDeviceToDevice, s));
+    act_dims[0] = h; act_dims[1] = w; act_dims[2] = c;
+    return 1;
+  };
+#define DVSG_TAP(stage, act, h, w, c)          \
+  do {                                         \
+    int t_ = tap(stage, act, h, w, c);         \
+    if (t_ < 0) return t_;                     \
+    if (t_ > 0) return DVSG_OK;                \
+  } while (0)
+#define DVSG_RUN(call)             \
+  do {                             \
+    if (int rc_ = (call)) return rc_; \
+  } while (0)
+
+  // root: conv1 (+ fused scale_RGB) -> bufA, max pool -> bufB
+  DVSG_RUN(launch_conv1(patches, net->conv1.wt, net->conv1.bias, ws.bufA, B, H, W, d.H1, d.W1, s));
+  DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
+  DVSG_RUN(launch_maxpool(ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
+  DVSG_TAP(1, ws.bufB, d.Hp, d.Wp, 64);
+
+  float *X = ws.bufB, *Y = ws.bufA;
+  int h = d.Hp, w = d.Wp;
+  int stage = 2;
+  for (const Unit &u : net->units) {
+    const int ho = (h - 1) / u.stride + 1, wo = (w - 1) / u.stride + 1;
+    const float *res = X;
+    int res_h = h, res_w = w, res_stride = u.stride;
+    if (u.has_shortcut) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
+      DVSG_RUN(run_conv(u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, s));
+      res = ws.bufS;
+      res_h = ho; res_w = wo; res_stride = 1;
+    }
+    DVSG_RUN(run_conv(u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, s));
+    DVSG_RUN(run_conv(u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, s));
+    DVSG_RUN(run_conv(u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, s));
+    h = ho; w = wo;
+    DVSG_TAP(stage, Y, h, w, u.depth);
+    ++stage;
+    float *tmp = X; X = Y; Y = tmp;
+  }
+
+  // global average pool (partial sums), then the dense head in chunks of <= 16 samples;
+  // partial layouts are [b][split][k] so a batch chunk is a pointer offset.
+  DVSG_RUN(launch_avgpool_partial(X, ws.pool_part, B, h * w, 2048, s));
+  const float inv_hw = 1.0f / (float)(h * w);
+  if (stop_stage == 18) {
+    const size_t bytes = (size_t)B * 2048 * sizeof(float);
+    if (bytes > act_out_bytes) return fail(DVSG_ERR_INVALID_ARG, "tap buffer %zu bytes < %zu", act_out_bytes, bytes);
+    DVSG_RUN(launch_dense_finalize(ws.pool_part, kPoolSplits, inv_hw, nullptr, act_out, B, 2048, s));
+    act_dims[0] = 1; act_dims[1] = 1; act_dims[2] = 2048;
+    return DVSG_OK;
+  }
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    const int bc = std::min(16, B - b0);
+    float *pa = ws.dpart0, *pb = ws.dpart1;
+    DVSG_RUN(launch_dense(ws.pool_part + (size_t)b0 * kPoolSplits * 2048, kPoolSplits, nullptr, inv_hw, 0,
+                          net->dense_w[0], pa, bc, 2048, 2048, s));
+    DVSG_RUN(launch_dense(pa, kDenseSplits, net->dense_b[0], 1.0f, 1, net->dense_w[1], pb, bc, 2048, 1024, s));
+    DVSG_RUN(launch_dense(pb, kDenseSplits, net->dense_b[1], 1.0f, 1, net->dense_w[2], pa, bc, 1024, 512, s));
+    DVSG_RUN(launch_dense(pa, kDenseSplits, net->dense_b[2], 1.0f, 1, net->dense_w[3], pb, bc, 512, 50, s));
+    DVSG_RUN(launch_dense_finalize(pb, kDenseSplits, 1.0f, net->dense_b[3], F_t + (size_t)b0 * 50, bc, 50, s));
+  }
+  return DVSG_OK;
+#undef DVSG_TAP
+#undef DVSG_RUN
+}
+
+}  // namespace
+}  // namespace dvsg
+
+extern "C" {
+
+int dvsg_locnet_create(int n_arrays, const char *const *names, const float *const *host_data, const int *ndims,
+                       const int64_t *dims, dvsg_locnet_t **out) {
+  DVSG_REQUIRE(names && host_data && ndims && dims && out && n_arrays > 0, "dvsg_locnet_create: bad arguments");
+  *out = nullptr;
+  ArrayMap m;
+  for (int i = 0; i < n_arrays; ++i) {
+    DVSG_REQUIRE(names[i] && host_data[i] && ndims[i] >= 1 && ndims[i] <= 4, "dvsg_locnet_create: bad array %d", i);
+    std::string name(names[i]);
+    if (name.size() > 2 && name.compare(name.size() - 2, 2, ":0") == 0) name.resize(name.size() - 2);
+    HostArray a;
+    a.data = host_data[i];
+    a.nd = ndims[i];
+    for (int j = 0; j < 4; ++j) a.dims[j] = j < a.nd ? dims[(size_t)i * 4 + j] : 1;
+    m[name] = a;
+  }
+  const std::string rn = std::string(kPrefix) + "resnet_v1_50";
+  auto it = m.find(rn + "/conv1/weights");
+  if (it == m.end()) return fail(DVSG_ERR_WEIGHTS, "checkpoint array missing: %s/conv1/weights", rn.c_str());
+  if (it->second.nd != 4) return fail(DVSG_ERR_WEIGHTS, "conv1/weights must be 4-D");
+  const int c_in = (int)it->second.dims[2];
+  if (c_in != kConv1Cin)
+    return fail(DVSG_ERR_UNSUPPORTED, "conv1 has %d input channels; this build supports the 7-frame window (21)", c_in);
+
+  dvsg_locnet *net = new dvsg_locnet();
+  net->c_in = c_in;
+  int rc = DVSG_OK;
+  auto bail = [&](int code) {
+    dvsg_locnet_destroy(net);
+    return code;
+  };
+  net->conv1 = ConvLayer{7, c_in, 64, 2, true};
+  if ((rc = make_conv1(net, m, rn + "/conv1", &net->conv1))) return bail(rc);
+  int depth_in = 64;
+  for (const BlockSpec &bs : kBlocks) {
+    for (int u = 1; u <= bs.units; ++u) {
+      Unit unit;
+      unit.base = bs.base;
+      unit.depth = bs.base * 4;
+      unit.stride = u == bs.units ? bs.last_stride : 1;
+      unit.has_shortcut = depth_in != unit.depth;
+      const std::string sc = rn + "/" + bs.name + "/unit_" + std::to_string(u) + "/bottleneck_v1";
+      if (unit.has_shortcut) {
+        if (unit.stride != 1) return bail(fail(DVSG_ERR_UNSUPPORTED, "strided shortcut conv not expected in resnet_v1_50"));
+        unit.shortcut = ConvLayer{1, depth_in, unit.depth, 1, false};
+        if ((rc = make_conv(net, m, sc + "/shortcut", &unit.shortcut))) return bail(rc);
+      }
+      unit.c1 = ConvLayer{1, depth_in, bs.base, 1, true};
+      unit.c2 = ConvLayer{3, bs.base, bs.base, unit.stride, true};
+      unit.c3 = ConvLayer{1, bs.base, unit.depth, 1, false};
+      if ((rc = make_conv(net, m, sc + "/conv1", &unit.c1))) return bail(rc);
+      if ((rc = make_conv(net, m, sc + "/conv2", &unit.c2))) return bail(rc);
+      if ((rc = make_conv(net, m, sc + "/conv3", &unit.c3))) return bail(rc);
+      net->units.push_back(unit);
+      depth_in = unit.depth;
+    }
+  }
+  for (int i = 0; i < 4; ++i) {
+    const std::string sc = std::string(kPrefix) + "df/dense" + std::to_string(i + 1);
+    const HostArray *W, *b;
+    if ((rc = find(m, sc + "/W", {kDenseDims[i][0], kDenseDims[i][1]}, &W))) return bail(rc);
+    if ((rc = find(m, sc + "/b", {kDenseDims[i][1]}, &b))) return bail(rc);
+    std::vector<float> hw(W->data, W->data + W->size()), hb(b->data, b->data + b->size());
+    if ((rc = upload(net, hw, &net->dense_w[i]))) return bail(rc);
+    if ((rc = upload(net, hb, &net->dense_b[i]))) return bail(rc);
+  }
+  std::vector<float> vs(50);  // model.py:105-110: 5x5 grid on [-1,1]^2, x fastest
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      vs[(i * 5 + j) * 2 + 0] = -1.0f + 0.5f * j;
+      vs[(i * 5 + j) * 2 + 1] = -1.0f + 0.5f * i;
+    }
+  if ((rc = upload(net, vs, &net->v_src))) return bail(rc);
+  *out = net;
+  return DVSG_OK;
+}
+
+int dvsg_locnet_destroy(dvsg_locnet_t *net) {
+  if (!net) return DVSG_OK;
+  for (void *p : net->allocs) (void)hipFree(p);
+  delete net;
+  return DVSG_OK;
+}
+
+int dvsg_locnet_in_channels(const dvsg_locnet_t *net) { return net ? net->c_in : 0; }
+
+int dvsg_locnet_workspace_bytes(const dvsg_locnet_t *net, int B, int H, int W, size_t *bytes) {
+  DVSG_REQUIRE(net && bytes, "dvsg_locnet_workspace_bytes: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0, "dvsg_locnet_workspace_bytes: bad shape B=%d H=%d W=%d", B, H, W);
+  *bytes = plan(nullptr, B, H, W).total;
+  return DVSG_OK;
+}
+
+int dvsg_locnet_forward_f32(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, float *F_t,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(F_t, "dvsg_locnet_forward_f32: NULL F_t");
+  return forward(net, patches, B, H, W, F_t, -1, nullptr, 0, nullptr, workspace, workspace_bytes, as_stream(stream));
+}
+
+int dvsg_locnet_forward_tap_f32(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
+                                float *act_out, size_t act_out_bytes, int *act_dims_host, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(act_out && act_dims_host, "dvsg_locnet_forward_tap_f32: NULL pointer");
+  DVSG_REQUIRE(stage >= 0 && stage <= 18, "dvsg_locnet_forward_tap_f32: stage %d outside [0,18]", stage);
+  return forward(net, patches, B, H, W, nullptr, stage, act_out, act_out_bytes, act_dims_host, workspace,
+                 workspace_bytes, as_stream(stream));
+}
+
+int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
+                       float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+  DVSG_REQUIRE(net && patches_t && u_t && s_t_pred && workspace, "dvsg_stabilize_f32: NULL pointer");
+  DVSG_REQUIRE(B > 0 && B <= 65535, "dvsg_stabilize_f32: B=%d out of range", B);
+  const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
+  if (ws.total > workspace_bytes)
+    return fail(DVSG_ERR_WORKSPACE, "dvsg_stabilize_f32: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
+  float *F = F_t ? F_t : ws.Ft;
+  if (int rc = forward(net, patches_t, B, H, W, F, -1, nullptr, 0, nullptr, workspace, workspace_bytes, as_stream(stream)))
+    return rc;
+  // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111)
+  if (int rc = tps_solve_impl(net->v_src, 0, F, 1, B, 25, ws.T, stream)) return rc;
+  return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,634 @@
+// Geometric warps of the DVSG hot path as gfx950 HIP kernels: thin-plate-spline solve,
+// fused TPS grid generation + sampler A, optical-flow warp (sampler C), and the affine /
+// projective / elastic spatial transformers over sampler B.
+//
+// All of these are HBM-bound gathers (24-32 algorithmic bytes per output pixel); none is
+// GEMM-shaped, so there is no MFMA here.  What matters: every store is a fully coalesced
+// 768-byte wave write (lane l owns pixel base+l, 12 B each), the per-sample transform
+// coefficients are staged once per workgroup in LDS and read back as wave-uniform
+// (broadcast) ds_read_b128, and the [B,P+3,H*W] basis the reference materialises
+// (ThinPlateSpline.py:92-111) lives only in registers.
+//
+// This translation unit is compiled with -ffp-contract=off: the reference graph is a chain
+// of separately rounded float32 mul / add ops, and keeping the same roundings lets the
+// parity tests compare source coordinates to the oracle within 1-2 ulp (only logf differs).
+#include "common.h"
+
+namespace dvsg {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxPts = 61;  // P + 3 <= 64
+
+// ----------------------------------------------------------------------------------------
+// TPS system solve: ThinPlateSpline.py:143-166.  One wave per batch sample, thread = row of
+// the (P+3)x(P+3) system, Gauss-Jordan with partial pivoting in float64 on the float32-built
+// matrix, two right-hand sides (x and y of the displaced control points).
+// ----------------------------------------------------------------------------------------
+constexpr int kSolveLd = 67;  // 64 + 2 rhs columns, +1 pad
+
+__global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__ coord,
+                                                       long coord_bstride,
+                                                       const float *__restrict__ rhs,
+                                                       int rhs_is_vector, int P,
+                                                       float *__restrict__ T) {
+  __shared__ double A[64 * kSolveLd];
+  __shared__ float cx[64], cy[64];
+  __shared__ int pivrow[64];
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int n = P + 3;
+  if (t < P) {
+    cx[t] = coord[b * coord_bstride + t * 2 + 0];
+    cy[t] = coord[b * coord_bstride + t * 2 + 1];
+  }
+  __syncthreads();
+  double *row = A + t * kSolveLd;
+  if (t < P) {
+    // W_0 = [p, r] (:156), p = [1, cx, cy] (:148), r = d2 * log(d2 + 1e-6) (:152-153)
+    row[0] = 1.0;
+    row[1] = (double)cx[t];
+    row[2] = (double)cy[t];
+    for (int j = 0; j < P; ++j) {
+      float dx = cx[t] - cx[j];
+      float dy = cy[t] - cy[j];
+      float d2 = dx * dx + dy * dy;
+      float r = d2 * logf(d2 + 1e-6f);
+      row[3 + j] = (double)r;
+    }
+    float rx = rhs[((size_t)b * P + t) * 2 + 0];
+    float ry = rhs[((size_t)b * P + t) * 2 + 1];
+    if (rhs_is_vector) {  // coord + vector in float32 (:161)
+      rx = cx[t] + rx;
+      ry = cy[t] + ry;
+    }
+    row[n] = (double)rx;
+    row[n + 1] = (double)ry;
+  } else if (t < n) {
+    // W_1 = [0_3x3, p^T] (:157); rhs padded with three zero rows (:161-162)
+    const int q = t - P;
+    row[0] = row[1] = row[2] = 0.0;
+    for (int j = 0; j < P; ++j) row[3 + j] = q == 0 ? 1.0 : (q == 1 ? (double)cx[j] : (double)cy[j]);
+    row[n] = 0.0;
+    row[n + 1] = 0.0;
+  }
+  __syncthreads();
+  bool used = false;
+  for (int k = 0; k < n; ++k) {
+    double v = (t < n && !used) ? fabs(row[k]) : -1.0;
+    int idx = t;
+    for (int off = 32; off > 0; off >>= 1) {
+      double ov = __shfl_xor(v, off);
+      int oi = __shfl_xor(idx, off);
+      if (ov > v || (ov == v && oi < idx)) {
+        v = ov;
+        idx = oi;
+      }
+    }
+    const int p = idx;
+    const double *prow = A + p * kSolveLd;
+    const double piv = prow[k];
+    if (t < n && t != p) {
+      const double f = row[k] / piv;
+      for (int c = k; c < n + 2; ++c) row[c] -= f * prow[c];
+    }
+    if (t == p) {
+      used = true;
+      pivrow[k] = p;
+    }
+    __syncthreads();
+  }
+  // T = (W^-1 tp)^T (:163-164): T[b][c][k]
+  if (t < n) {
+    const double *prow = A + pivrow[t] * kSolveLd;
+    const double piv = prow[t];
+    T[((size_t)b * 2 + 0) * n + t] = (float)(prow[n] / piv);
+    T[((size_t)b * 2 + 1) * n + t] = (float)(prow[n + 1] / piv);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// Samplers.
+// ----------------------------------------------------------------------------------------
+template <int C>
+struct Pix {
+  float v[C];
+};
+
+template <int C>
+__device__ __forceinline__ Pix<C> load_pix(const float *__restrict__ p) {
+  Pix<C> r;
+#pragma unroll
+  for (int c = 0; c < C; ++c) r.v[c] = p[c];
+  return r;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Guarded float -> int conversion (floor already applied): out-of-range source coordinates
+// are garbage in the reference too (tf.cast saturates to INT_MIN on x86); keep it defined.
+__device__ __forceinline__ int f2i(float f) {
+  f = f < -1073741824.f ? -1073741824.f : (f > 1073741824.f ? 1073741824.f : f);
+  return (int)f;
+}
+
+// Sampler A (ThinPlateSpline.py:30-90): normalised (xs, ys) -> (x+1)*W/2, indices clipped to
+// the image BEFORE the weights are formed, so out-of-range taps coincide and cancel.
+template <int C>
+__device__ __forceinline__ void sample_a(const float *__restrict__ img /* [H,W,C] of this sample */,
+                                         int H, int W, int Cn, float xs, float ys,
+                                         float *__restrict__ dst) {
+  const float x = ((xs + 1.0f) * (float)W) / 2.0f;  // :48
+  const float y = ((ys + 1.0f) * (float)H) / 2.0f;  // :49
+  int x0 = f2i(floorf(x));
+  int y0 = f2i(floorf(y));
+  int x1 = x0 + 1;
+  int y1 = y0 + 1;
+  x0 = clampi(x0, 0, W - 1);  // :57-60
+  x1 = clampi(x1, 0, W - 1);
+  y0 = clampi(y0, 0, H - 1);
+  y1 = clampi(y1, 0, H - 1);
+  const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+  const float wa = (x1f - x) * (y1f - y);  // :85-88
+  const float wb = (x1f - x) * (y - y0f);
+  const float wc = (x - x0f) * (y1f - y);
+  const float wd = (x - x0f) * (y - y0f);
+  const float *pa = img + ((size_t)y0 * W + x0) * Cn;  // (x0,y0)
+  const float *pb = img + ((size_t)y1 * W + x0) * Cn;  // (x0,y1)
+  const float *pc = img + ((size_t)y0 * W + x1) * Cn;  // (x1,y0)
+  const float *pd = img + ((size_t)y1 * W + x1) * Cn;  // (x1,y1)
+  if (C > 0) {
+    const Pix<(C > 0 ? C : 1)> a = load_pix<(C > 0 ? C : 1)>(pa), bq = load_pix<(C > 0 ? C : 1)>(pb),
+                               cq = load_pix<(C > 0 ? C : 1)>(pc), d = load_pix<(C > 0 ? C : 1)>(pd);
+#pragma unroll
+    for (int c = 0; c < C; ++c) dst[c] = ((wa * a.v[c] + wb * bq.v[c]) + wc * cq.v[c]) + wd * d.v[c];  // :89
+  } else {
+    for (int c = 0; c < Cn; ++c) dst[c] = ((wa * pa[c] + wb * pb[c]) + wc * pc[c]) + wd * pd[c];
+  }
+}
+
+// Samplers B and C share this tail (spatial_transformer.py:517-562,
+// warp_with_optical_flow.py:128-173): (x, y) in unpadded pixel units, clamped to [-1,W] /
+// [-1,H], +1 into the zero-ringed image, floor, upper index min()-ed, weights from the
+// UNclamped x0+1.  The ring is never materialised: a tap on it reads as 0.
+template <int C>
+__device__ __forceinline__ void sample_padded(const float *__restrict__ img, int H, int W, int Cn,
+                                              float x, float y, float *__restrict__ dst) {
+  const float wf = (float)W, hf = (float)H;
+  x = fminf(fmaxf(x, -1.0f), wf);  // (W-1)+1
+  y = fminf(fmaxf(y, -1.0f), hf);
+  x = x + 1.0f;
+  y = y + 1.0f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int x1 = (int)fminf(x1f, wf + 1.0f);
+  const int y1 = (int)fminf(y1f, hf + 1.0f);
+  const float w00 = (x1f - x) * (y1f - y);
+  const float w01 = (x - x0f) * (y1f - y);
+  const float w10 = (x1f - x) * (y - y0f);
+  const float w11 = (x - x0f) * (y - y0f);
+  const bool vx0 = x0 >= 1 && x0 <= W, vx1 = x1 >= 1 && x1 <= W;
+  const bool vy0 = y0 >= 1 && y0 <= H, vy1 = y1 >= 1 && y1 <= H;
+  // taps on the ring are never dereferenced; signed offsets keep the arithmetic defined
+  const float *p00 = img + ((long)(y0 - 1) * W + (x0 - 1)) * Cn;
+  const float *p01 = img + ((long)(y0 - 1) * W + (x1 - 1)) * Cn;
+  const float *p10 = img + ((long)(y1 - 1) * W + (x0 - 1)) * Cn;
+  const float *p11 = img + ((long)(y1 - 1) * W + (x1 - 1)) * Cn;
+  if (C > 0) {
+    constexpr int CC = C > 0 ? C : 1;
+    Pix<CC> z;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) z.v[c] = 0.f;
+    const Pix<CC> a = (vx0 && vy0) ? load_pix<CC>(p00) : z;
+    const Pix<CC> bq = (vx1 && vy0) ? load_pix<CC>(p01) : z;
+    const Pix<CC> cq = (vx0 && vy1) ? load_pix<CC>(p10) : z;
+    const Pix<CC> d = (vx1 && vy1) ? load_pix<CC>(p11) : z;
+#pragma unroll
+    for (int c = 0; c < C; ++c) dst[c] = ((w00 * a.v[c] + w01 * bq.v[c]) + w10 * cq.v[c]) + w11 * d.v[c];
+  } else {
+    for (int c = 0; c < Cn; ++c) {
+      const float a = (vx0 && vy0) ? p00[c] : 0.f;
+      const float bq = (vx1 && vy0) ? p01[c] : 0.f;
+      const float cq = (vx0 && vy1) ? p10[c] : 0.f;
+      const float d = (vx1 && vy1) ? p11[c] : 0.f;
+      dst[c] = ((w00 * a + w01 * bq) + w10 * cq) + w11 * d;
+    }
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void store_pix(float *__restrict__ out, size_t pix, int Cn,
+                                          const float *__restrict__ v) {
+  if (C > 0) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[pix * C + c] = v[c];
+  } else {
+    for (int c = 0; c < Cn; ++c) out[pix * Cn + c] = v[c];
+  }
+}
+
+constexpr int kMaxGenericC = 64;
+
+// ----------------------------------------------------------------------------------------
+// Fused TPS grid generation + sampler A (ThinPlateSpline.py:92-141).
+// Thread = one output column, PPT consecutive rows: (x_t - px)^2 is shared by the rows, and
+// each of the P control points costs one broadcast ds_read_b128 {px, py, T0, T1}.
+// ----------------------------------------------------------------------------------------
+template <int C, int PPT>
+__global__ __launch_bounds__(kThreads) void tps_warp_kernel(
+    const float *__restrict__ U, const float *__restrict__ coord, long coord_bstride,
+    const float *__restrict__ T, int H, int W, int Cn, int P, int out_h, int out_w, float step_x,
+    float step_y, float *__restrict__ out,
+    float *__restrict__ xs_out, float *__restrict__ ys_out) {
+  __shared__ float4 sp[64];  // {px, py, T[0][3+k], T[1][3+k]}
+  __shared__ float sa[6];    // T[0][0..2], T[1][0..2]
+  const int b = blockIdx.z;
+  const int n = P + 3;
+  const int t = threadIdx.x;
+  if (t < P) {
+    sp[t] = make_float4(coord[b * coord_bstride + t * 2], coord[b * coord_bstride + t * 2 + 1],
+                        T[((size_t)b * 2) * n + 3 + t], T[((size_t)b * 2 + 1) * n + 3 + t]);
+  } else if (t >= 64 && t < 70) {
+    const int q = t - 64;
+    sa[q] = T[((size_t)b * 2 + q / 3) * n + q % 3];
+  }
+  __syncthreads();
+  const int j = blockIdx.x * kThreads + t;
+  const int i0 = blockIdx.y * PPT;
+  if (j >= out_w) return;
+  const float x_t = -1.0f + step_x * (float)j;  // tf.linspace: start + step * i (:94)
+  float y_t[PPT], xs[PPT], ys[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    y_t[r] = -1.0f + step_y * (float)(i0 + r);  // :96
+    // T . [1, x_t, y_t, ...] accumulated in k order (:129)
+    xs[r] = (sa[0] + sa[1] * x_t) + sa[2] * y_t[r];
+    ys[r] = (sa[3] + sa[4] * x_t) + sa[5] * y_t[r];
+  }
+  for (int k = 0; k < P; ++k) {
+    const float4 c = sp[k];
+    const float dx = x_t - c.x;
+    const float dx2 = dx * dx;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const float dy = y_t[r] - c.y;
+      const float d2 = dx2 + dy * dy;              // :104
+      const float rk = d2 * logf(d2 + 1e-6f);      // :105
+      xs[r] = xs[r] + c.z * rk;
+      ys[r] = ys[r] + c.w * rk;
+    }
+  }
+  const float *img = U ? U + (size_t)b * H * W * Cn : nullptr;
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    const int i = i0 + r;
+    if (i >= out_h) break;
+    const size_t pix = ((size_t)b * out_h + i) * out_w + j;
+    if (xs_out) xs_out[pix] = xs[r];
+    if (ys_out) ys_out[pix] = ys[r];
+    if (img) {
+      float v[C > 0 ? C : kMaxGenericC];
+      sample_a<C>(img, H, W, Cn, xs[r], ys[r], v);
+      store_pix<C>(out, pix, Cn, v);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// Sampler B / C front ends: flow (warp_with_optical_flow.py:106-120), explicit coords,
+// affine (spatial_transformer.py:74-91), projective (:423-452), elastic (:276-296).
+// ----------------------------------------------------------------------------------------
+enum Src { kFlow = 0, kCoords = 1, kAffine = 2, kProjective = 3, kElastic = 4 };
+
+struct StnParams {
+  const float *im;      // [B,H,W,C] or null (grid only)
+  const float *a;       // flow [B,H,W,2] | x_s | theta
+  const float *b;       // y_s | L_inv [n,n+3]
+  const float *c;       // source_points [2,n]
+  float *out;           // [B,out_h,out_w,C]
+  float *xs_out, *ys_out;
+  int H, W, Cn, out_h, out_w, n;
+  float step_x, step_y;
+};
+
+template <int SRC, int C, int PPT>
+__global__ __launch_bounds__(kThreads) void stn_kernel(StnParams p) {
+  __shared__ float sc[2 * 64];   // elastic coefficients [2][n+3]
+  __shared__ float ssrc[2 * 64]; // elastic source points [2][n]
+  __shared__ float sth[9];
+  const int b = blockIdx.z;
+  const int t = threadIdx.x;
+  if (SRC == kAffine) {
+    if (t < 6) sth[t] = p.a[(size_t)b * 6 + t];
+    __syncthreads();
+  } else if (SRC == kProjective) {
+    if (t < 9) sth[t] = t < 8 ? p.a[(size_t)b * 8 + t] : 1.0f;  // :430
+    __syncthreads();
+  } else if (SRC == kElastic) {
+    const int n = p.n, m = p.n + 3;
+    if (t < 2 * m) {
+      // coefficients = theta @ L_inv (:284), k order
+      const int r = t / m, q = t % m;
+      const float *th = p.a + ((size_t)b * 2 + r) * n;
+      float acc = th[0] * p.b[q];
+      for (int k = 1; k < n; ++k) acc = acc + th[k] * p.b[(size_t)k * m + q];
+      sc[r * 64 + q] = acc;
+    }
+    if (t < 2 * n) ssrc[(t / n) * 64 + t % n] = p.c[t];
+    __syncthreads();
+  }
+  const int j = blockIdx.x * kThreads + t;
+  const int i0 = blockIdx.y * PPT;
+  if (j >= p.out_w) return;
+  const float *img = p.im ? p.im + (size_t)b * p.H * p.W * p.Cn : nullptr;
+  const float x_t = -1.0f + p.step_x * (float)j;
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    const int i = i0 + r;
+    if (i >= p.out_h) break;
+    const size_t pix = ((size_t)b * p.out_h + i) * p.out_w + j;
+    const float y_t = -1.0f + p.step_y * (float)i;
+    float xs, ys, x, y;
+    if (SRC == kFlow) {
+      const float2 f = reinterpret_cast<const float2 *>(p.a)[pix];
+      x = (float)j + f.x;  // :117-119
+      y = (float)i + f.y;
+      xs = x;
+      ys = y;
+    } else {
+      if (SRC == kCoords) {
+        xs = p.a[pix];
+        ys = p.b[pix];
+      } else if (SRC == kAffine) {
+        xs = (sth[0] * x_t + sth[1] * y_t) + sth[2];  // theta . [x_t; y_t; 1] in k order (:85)
+        ys = (sth[3] * x_t + sth[4] * y_t) + sth[5];
+      } else if (SRC == kProjective) {
+        const float xq = (sth[0] * x_t + sth[1] * y_t) + sth[2];  // :438
+        const float yq = (sth[3] * x_t + sth[4] * y_t) + sth[5];
+        const float zq = (sth[6] * x_t + sth[7] * y_t) + sth[8];
+        xs = zq != 0.f ? xq / zq : 0.f;  // tf.div_no_nan (:446-447)
+        ys = zq != 0.f ? yq / zq : 0.f;
+      } else {  // elastic: coefficients . [x; y; 1; U_0..U_{n-1}] (:288-290)
+        xs = (sc[0] * x_t + sc[1] * y_t) + sc[2];
+        ys = (sc[64] * x_t + sc[65] * y_t) + sc[66];
+        for (int k = 0; k < p.n; ++k) {
+          const float dx = x_t - ssrc[k];
+          const float dy = y_t - ssrc[64 + k];
+          const float rsq = dx * dx + dy * dy;              // :301
+          const float u = rsq == 0.f ? 0.f : rsq * logf(rsq);  // log(0) -> 0 via is_inf (:302-304)
+          xs = xs + sc[3 + k] * u;
+          ys = ys + sc[64 + 3 + k] * u;
+        }
+      }
+      // scale to [0, W-1] (:515-516)
+      x = ((xs + 1.0f) / 2.0f) * ((float)p.W - 1.0f);
+      y = ((ys + 1.0f) / 2.0f) * ((float)p.H - 1.0f);
+    }
+    if (SRC != kFlow && SRC != kCoords) {
+      if (p.xs_out) p.xs_out[pix] = xs;
+      if (p.ys_out) p.ys_out[pix] = ys;
+    }
+    if (img) {
+      float v[C > 0 ? C : kMaxGenericC];
+      sample_padded<C>(img, p.H, p.W, p.Cn, x, y, v);
+      store_pix<C>(p.out, pix, p.Cn, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void scale_rgb_kernel(const float *__restrict__ in,
+                                                            float *__restrict__ out, size_t npix,
+                                                            int C) {
+  // networks.py:6-16: out group g' = 2 - g, mean[g'] subtracted after the x255 scale.
+  const int G = C / 3;
+  const size_t total = npix * C;
+  for (size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * kThreads) {
+    const int c = (int)(e % C);
+    const size_t pix = e / C;
+    const int g = c / G;            // output group
+    const int src = (2 - g) * G + c % G;
+    const float mean = g == 0 ? 103.939f : (g == 1 ? 116.779f : 123.68f);
+    out[e] = in[pix * C + src] * 255.0f - mean;
+  }
+}
+
+inline float lin_step(int n) { return n > 1 ? (1.0f - (-1.0f)) / (float)(n - 1) : 0.0f; }
+
+template <int SRC>
+int launch_stn(StnParams p, int B, hipStream_t s, const char *what) {
+  constexpr int PPT = 2;
+  dim3 grid(ceil_div(p.out_w, kThreads), ceil_div(p.out_h, PPT), B);
+  if (p.Cn == 3)
+    hipLaunchKernelGGL((stn_kernel<SRC, 3, PPT>), grid, dim3(kThreads), 0, s, p);
+  else if (p.Cn == 1)
+    hipLaunchKernelGGL((stn_kernel<SRC, 1, PPT>), grid, dim3(kThreads), 0, s, p);
+  else
+    hipLaunchKernelGGL((stn_kernel<SRC, 0, PPT>), grid, dim3(kThreads), 0, s, p);
+  return check_launch(what);
+}
+
+int check_image_args(const char *fn, int B, int H, int W, int C, int out_h, int out_w) {
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && out_h > 0 && out_w > 0,
+               "%s: sizes must be positive (B=%d H=%d W=%d C=%d out=%dx%d)", fn, B, H, W, C, out_h, out_w);
+  DVSG_REQUIRE(C <= kMaxGenericC, "%s: C=%d exceeds the supported maximum %d", fn, C, kMaxGenericC);
+  DVSG_REQUIRE(B <= 65535, "%s: B=%d exceeds the grid limit 65535", fn, B);
+  DVSG_REQUIRE((long)H * W < (1L << 31) && (long)out_h * out_w < (1L << 31), "%s: image too large", fn);
+  return DVSG_OK;
+}
+
+}  // namespace
+
+// coord_bstride = 0 broadcasts one set of control points over the batch (model.py:111 tiles
+// the constant V_src; the fused evaluation graph does not materialise the tile).
+int tps_solve_impl(const float *coord, long coord_bstride, const float *rhs, int rhs_is_vector, int B,
+                   int P, float *T, void *stream) {
+  DVSG_REQUIRE(coord && rhs && T, "dvsg_tps_solve_f32: NULL pointer");
+  DVSG_REQUIRE(B > 0, "dvsg_tps_solve_f32: B=%d must be positive", B);
+  DVSG_REQUIRE(P >= 3 && P <= kMaxPts, "dvsg_tps_solve_f32: P=%d outside [3,%d]", P, kMaxPts);
+  hipLaunchKernelGGL(tps_solve_kernel, dim3(B), dim3(64), 0, as_stream(stream), coord, coord_bstride, rhs,
+                     rhs_is_vector, P, T);
+  return check_launch("tps_solve_kernel");
+}
+
+int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const float *T, int B, int H,
+                  int W, int C, int P, int out_h, int out_w, float *out, float *x_s, float *y_s,
+                  void *stream) {
+  DVSG_REQUIRE(coord && T, "dvsg_tps_warp_f32: NULL coord/T");
+  DVSG_REQUIRE((U == nullptr) == (out == nullptr), "dvsg_tps_warp_f32: U and out must both be given or both NULL");
+  DVSG_REQUIRE(U || x_s || y_s, "dvsg_tps_warp_f32: nothing to compute");
+  DVSG_REQUIRE(P >= 1 && P <= kMaxPts, "dvsg_tps_warp_f32: P=%d outside [1,%d]", P, kMaxPts);
+  if (int rc = check_image_args("dvsg_tps_warp_f32", B, U ? H : 1, U ? W : 1, U ? C : 1, out_h, out_w)) return rc;
+  constexpr int PPT = 4;
+  dim3 grid(ceil_div(out_w, kThreads), ceil_div(out_h, PPT), B);
+  const float sx = lin_step(out_w), sy = lin_step(out_h);
+  hipStream_t s = as_stream(stream);
+  if (!U) C = 3;
+  if (C == 3)
+    hipLaunchKernelGGL((tps_warp_kernel<3, PPT>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
+                       C, P, out_h, out_w, sx, sy, out, x_s, y_s);
+  else if (C == 1)
+    hipLaunchKernelGGL((tps_warp_kernel<1, PPT>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
+                       C, P, out_h, out_w, sx, sy, out, x_s, y_s);
+  else
+    hipLaunchKernelGGL((tps_warp_kernel<0, PPT>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
+                       C, P, out_h, out_w, sx, sy, out, x_s, y_s);
+  return check_launch("tps_warp_kernel");
+}
+
+}  // namespace dvsg
+
+using namespace dvsg;
+
+extern "C" {
+
+int dvsg_tps_solve_f32(const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
+                       float *T, void *stream) {
+  return tps_solve_impl(coord, (long)P * 2, rhs, rhs_is_vector, B, P, T, stream);
+}
+
+int dvsg_tps_warp_f32(const float *U, const float *coord, const float *T, int B, int H, int W,
+                      int C, int P, int out_h, int out_w, float *out, float *x_s, float *y_s,
+                      void *stream) {
+  return tps_warp_impl(U, coord, (long)P * 2, T, B, H, W, C, P, out_h, out_w, out, x_s, y_s, stream);
+}
+
+int dvsg_flow_warp_f32(const float *im, const float *flow, int B, int H, int W, int C, float *out,
+                       void *stream) {
+  DVSG_REQUIRE(im && flow && out, "dvsg_flow_warp_f32: NULL pointer");
+  if (int rc = check_image_args("dvsg_flow_warp_f32", B, H, W, C, H, W)) return rc;
+  StnParams p{};
+  p.im = im; p.a = flow; p.out = out;
+  p.H = H; p.W = W; p.Cn = C; p.out_h = H; p.out_w = W;
+  return launch_stn<kFlow>(p, B, as_stream(stream), "flow_warp_kernel");
+}
+
+int dvsg_stn_sample_f32(const float *im, const float *x_s, const float *y_s, int B, int H, int W,
+                        int C, int out_h, int out_w, float *out, void *stream) {
+  DVSG_REQUIRE(im && x_s && y_s && out, "dvsg_stn_sample_f32: NULL pointer");
+  if (int rc = check_image_args("dvsg_stn_sample_f32", B, H, W, C, out_h, out_w)) return rc;
+  StnParams p{};
+  p.im = im; p.a = x_s; p.b = y_s; p.out = out;
+  p.H = H; p.W = W; p.Cn = C; p.out_h = out_h; p.out_w = out_w;
+  return launch_stn<kCoords>(p, B, as_stream(stream), "stn_sample_kernel");
+}
+
+static int grid_common(const char *fn, StnParams &p, const float *im, int B, int H, int W, int C,
+                       int out_h, int out_w, float *out, float *x_s, float *y_s) {
+  DVSG_REQUIRE((im == nullptr) == (out == nullptr), "%s: im and out must both be given or both NULL", fn);
+  DVSG_REQUIRE(im || x_s || y_s, "%s: nothing to compute", fn);
+  if (int rc = check_image_args(fn, B, im ? H : 1, im ? W : 1, im ? C : 1, out_h, out_w)) return rc;
+  p.im = im; p.out = out; p.xs_out = x_s; p.ys_out = y_s;
+  p.H = H; p.W = W; p.Cn = im ? C : 1; p.out_h = out_h; p.out_w = out_w;
+  p.step_x = lin_step(out_w);
+  p.step_y = lin_step(out_h);
+  return DVSG_OK;
+}
+
+int dvsg_grid_affine_f32(const float *theta, const float *im, int B, int H, int W, int C, int out_h,
+                         int out_w, float *out, float *x_s, float *y_s, void *stream) {
+  DVSG_REQUIRE(theta, "dvsg_grid_affine_f32: NULL theta");
+  StnParams p{};
+  if (int rc = grid_common("dvsg_grid_affine_f32", p, im, B, H, W, C, out_h, out_w, out, x_s, y_s)) return rc;
+  p.a = theta;
+  return launch_stn<kAffine>(p, B, as_stream(stream), "stn_affine_kernel");
+}
+
+int dvsg_grid_projective_f32(const float *theta, const float *im, int B, int H, int W, int C,
+                             int out_h, int out_w, float *out, float *x_s, float *y_s, void *stream) {
+  DVSG_REQUIRE(theta, "dvsg_grid_projective_f32: NULL theta");
+  StnParams p{};
+  if (int rc = grid_common("dvsg_grid_projective_f32", p, im, B, H, W, C, out_h, out_w, out, x_s, y_s)) return rc;
+  p.a = theta;
+  return launch_stn<kProjective>(p, B, as_stream(stream), "stn_projective_kernel");
+}
+
+int dvsg_grid_elastic_f32(const float *theta_abs, const float *L_inv, const float *source_points,
+                          int n, const float *im, int B, int H, int W, int C, int out_h, int out_w,
+                          float *out, float *x_s, float *y_s, void *stream) {
+  DVSG_REQUIRE(theta_abs && L_inv && source_points, "dvsg_grid_elastic_f32: NULL pointer");
+  DVSG_REQUIRE(n >= 1 && n <= kMaxPts, "dvsg_grid_elastic_f32: n=%d outside [1,%d]", n, kMaxPts);
+  StnParams p{};
+  if (int rc = grid_common("dvsg_grid_elastic_f32", p, im, B, H, W, C, out_h, out_w, out, x_s, y_s)) return rc;
+  p.a = theta_abs; p.b = L_inv; p.c = source_points; p.n = n;
+  return launch_stn<kElastic>(p, B, as_stream(stream), "stn_elastic_kernel");
+}
+
+int dvsg_elastic_constants_f32(int grid_size, float *source_points_host, float *L_inv_host) {
+  DVSG_REQUIRE(source_points_host && L_inv_host, "dvsg_elastic_constants_f32: NULL pointer");
+  const int n = grid_size * grid_size;
+  DVSG_REQUIRE(grid_size >= 2 && n <= kMaxPts, "dvsg_elastic_constants_f32: grid_size=%d unsupported", grid_size);
+  const int m = n + 3;
+  // source points: meshgrid(linspace(-1,1,g), linspace(-1,1,g)), x fastest (:313-322)
+  const float step = lin_step(grid_size);
+  for (int i = 0; i < grid_size; ++i)
+    for (int j = 0; j < grid_size; ++j) {
+      source_points_host[i * grid_size + j] = -1.0f + step * (float)j;
+      source_points_host[n + i * grid_size + j] = -1.0f + step * (float)i;
+    }
+  const float *sx = source_points_host, *sy = source_points_host + n;
+  // L (:339-346), built in float32 like the reference, inverted in float64.
+  static thread_local double L[64 * 64], Li[64 * 64];
+  for (int i = 0; i < m * m; ++i) L[i] = 0.0;
+  for (int j = 0; j < n; ++j) {
+    L[0 * m + 3 + j] = sx[j];
+    L[1 * m + 3 + j] = sy[j];
+    L[2 * m + 3 + j] = 1.0;
+  }
+  L[2 * m + 2] = 1.0;  // L_mid = [0, 0, 1, 1...1]
+  for (int i = 0; i < n; ++i) {
+    double *row = L + (size_t)(3 + i) * m;
+    row[0] = sx[i];
+    row[1] = sy[i];
+    row[2] = 1.0;
+    for (int j = 0; j < n; ++j) {
+      const float dx = sx[i] - sx[j], dy = sy[i] - sy[j];
+      const float rsq = dx * dx + dy * dy;
+      row[3 + j] = rsq == 0.f ? 0.0 : (double)(rsq * logf(rsq));
+    }
+  }
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) Li[i * m + j] = i == j ? 1.0 : 0.0;
+  for (int k = 0; k < m; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < m; ++i)
+      if (fabs(L[i * m + k]) > fabs(L[piv * m + k])) piv = i;
+    if (L[piv * m + k] == 0.0) return fail(DVSG_ERR_INVALID_ARG, "dvsg_elastic_constants_f32: singular L");
+    if (piv != k)
+      for (int c = 0; c < m; ++c) {
+        double tmp = L[k * m + c]; L[k * m + c] = L[piv * m + c]; L[piv * m + c] = tmp;
+        tmp = Li[k * m + c]; Li[k * m + c] = Li[piv * m + c]; Li[piv * m + c] = tmp;
+      }
+    const double d = L[k * m + k];
+    for (int c = 0; c < m; ++c) {
+      L[k * m + c] /= d;
+      Li[k * m + c] /= d;
+    }
+    for (int i = 0; i < m; ++i) {
+      if (i == k) continue;
+      const double f = L[i * m + k];
+      if (f == 0.0) continue;
+      for (int c = 0; c < m; ++c) {
+        L[i * m + c] -= f * L[k * m + c];
+        Li[i * m + c] -= f * Li[k * m + c];
+      }
+    }
+  }
+  // L_inv = transpose(inverse(L)[:, 3:]) -> [n, m] (:358)
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < m; ++i) L_inv_host[(size_t)j * m + i] = (float)Li[(size_t)i * m + 3 + j];
+  return DVSG_OK;
+}
+
+int dvsg_scale_rgb_f32(const float *rgb, int B, int H, int W, int C, float *out, void *stream) {
+  DVSG_REQUIRE(rgb && out, "dvsg_scale_rgb_f32: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 3 == 0,
+               "dvsg_scale_rgb_f32: bad shape B=%d H=%d W=%d C=%d (C must be a positive multiple of 3)", B, H, W, C);
+  const size_t npix = (size_t)B * H * W;
+  const int blocks = (int)((npix * C + kThreads - 1) / kThreads < 8192 ? (npix * C + kThreads - 1) / kThreads : 8192);
+  hipLaunchKernelGGL(scale_rgb_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), rgb, out, npix, C);
+  return check_launch("scale_rgb_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""Drop-in for the inference part of the reference's networks.py on MI355X.
+
+`scale_RGB(rgb)` (networks.py:6-16) and `localizationNet(input, param_dim, is_train=False,
+reuse=False, scope=...) -> [B, param_dim, 2]` (networks.py:30-46).  The reference builds TF
+variables under a scope and fills them from a checkpoint through the session; here the
+scope maps to a `LocNet` handle created from the same checkpoint arrays
+(`load_localizationNet`).  Training (`is_train=True`) and the correlationNet branch are out
+of scope.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, weights as _weights
+from ._tensor import as_dev, device, empty, like_input, ptr, stream
+
+_nets = {}
+
+
+def scale_RGB(rgb):
+    """networks.py:6-16 (standalone op; inside localizationNet it is fused into conv1)."""
+    t = as_dev(rgb)
+    B, H, W, C = t.shape
+    out = empty(t.shape, t)
+    _lib.call("dvsg_scale_rgb_f32", ptr(t), B, H, W, C, ptr(out), stream())
+    return like_input(out, rgb)
+
+
+class LocNet(object):
+    """Owns the device-side network (`dvsg_locnet_t`) and a growable workspace."""
+
+    def __init__(self, weights):
+        device()
+        w = _weights.validate(weights)
+        names = sorted(w)
+        n = len(names)
+        self._keep = [np.ascontiguousarray(w[k], dtype=np.float32) for k in names]
+        c_names = (ctypes.c_char_p * n)(*[k.encode() for k in names])
+        c_data = (ctypes.c_void_p * n)(*[a.ctypes.data for a in self._keep])
+        c_nd = (ctypes.c_int * n)(*[a.ndim for a in self._keep])
+        dims = np.ones((n, 4), dtype=np.int64)
+        for i, a in enumerate(self._keep):
+            dims[i, :a.ndim] = a.shape
+        handle = ctypes.c_void_p()
+        _lib.call("dvsg_locnet_create", n, c_names, c_data, c_nd,
+                  dims.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), ctypes.byref(handle))
+        self.handle = handle
+        self._keep = None  # the library copied everything to the device
+        self._ws = None
+        self.in_channels = _lib.load().dvsg_locnet_in_channels(self.handle)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().dvsg_locnet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace(self, B, H, W):
+        need = ctypes.c_size_t()
+        _lib.call("dvsg_locnet_workspace_bytes", self.handle, B, H, W, ctypes.byref(need))
+        if self._ws is None or self._ws.numel() < need.value:
+            import torch
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device())
+        return self._ws, need.value
+
+    def forward(self, patches, param_dim=25):
+        t = as_dev(patches)
+        B, H, W, C = t.shape
+        if C != self.in_channels:
+            raise ValueError("localizationNet was loaded for %d input channels, got %d" % (self.in_channels, C))
+        if param_dim != 25:
+            raise ValueError("the reference's dense4 has 50 outputs: param_dim must be 25")
+        ws, nbytes = self.workspace(B, H, W)
+        F = empty((B, param_dim, 2), t)
+        _lib.call("dvsg_locnet_forward_f32", self.handle, ptr(t), B, H, W, ptr(F), ptr(ws), nbytes, stream())
+        return F
+
+    def tap(self, patches, stage):
+        """Parity hook: activation after `stage` (0 conv1, 1 pool1, 2..17 units, 18 pool5)."""
+        t = as_dev(patches)
+        B, H, W, C = t.shape
+        ws, nbytes = self.workspace(B, H, W)
+        h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        cap = B * h1 * w1 * 64
+        buf = empty((cap,), t)
+        dims = (ctypes.c_int * 3)()
+        _lib.call("dvsg_locnet_forward_tap_f32", self.handle, ptr(t), B, H, W, int(stage), ptr(buf), cap * 4,
+                  dims, ptr(ws), nbytes, stream())
+        h, w, c = dims[0], dims[1], dims[2]
+        return buf[:B * h * w * c].reshape(B, h, w, c)
+
+
+def load_localizationNet(weights, scope="stabNet/localizationNet"):
+    """Create (or replace) the network living under `scope` from checkpoint arrays keyed by
+    the reference's variable names (ckpt_manager.py:33)."""
+    _nets[scope] = LocNet(weights)
+    return _nets[scope]
+
+
+def localizationNet(input, param_dim, is_train=False, reuse=False, scope="stabNet/localizationNet"):
+    """networks.py:30-46."""
+    if is_train:
+        raise NotImplementedError("training graph is out of scope; is_train must be False (model.py:99)")
+    key = scope if isinstance(scope, str) else getattr(scope, "name", str(scope))
+    if key not in _nets:
+        raise _lib.DvsgError("no weights loaded for scope %r: call load_localizationNet(weights) first "
+                             "(the reference would silently run on random weights, ckpt_manager.py:21-22)" % key)
+    F = _nets[key].forward(input, param_dim)
+    return like_input(F, input)

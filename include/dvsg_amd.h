@@ -1,0 +1,157 @@
+/*
+ * dvsg_amd.h -- C ABI of libdvsg_amd.so: the MI355X (gfx950) implementation of the
+ * coupe.DVSG per-frame inference hot path.
+ *
+ * The reference has no FFI / plugin interface: its boundary is a set of Python callables
+ * taking TF tensors.  Each entry point below replaces the TF
+ * sub-graph built by the reference function it cites; the Python facade
+ * (the coupe.dvsg_amd Python package) keeps the reference's names / argument order / return tuples and
+ * forwards to these.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (DVSG_OK) or a negative dvsg_status; it never throws or
+ *     aborts across the ABI.  dvsg_last_error_string() describes the calling thread's last
+ *     failure.
+ *   - every tensor argument is a CALLER-OWNED DEVICE pointer to dense float32 data in the
+ *     reference's layout (NHWC images, values as the reference feeds them) unless a
+ *     parameter is documented as "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All
+ *     calls are asynchronous and stream-ordered; none allocates, frees or synchronises.
+ *     Calls on distinct streams are re-entrant as long as their output / workspace buffers
+ *     are distinct.
+ *   - optional outputs may be NULL.
+ */
+#ifndef DVSG_AMD_H
+#define DVSG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVSG_ABI_VERSION 1
+
+typedef enum dvsg_status {
+  DVSG_OK = 0,
+  DVSG_ERR_INVALID_ARG = -1, /* NULL pointer, non-positive size, unsupported shape        */
+  DVSG_ERR_HIP = -2,         /* a HIP runtime call failed; see dvsg_last_error_string()    */
+  DVSG_ERR_WORKSPACE = -3,   /* workspace too small or misaligned                          */
+  DVSG_ERR_WEIGHTS = -4,     /* checkpoint array missing / wrong shape                     */
+  DVSG_ERR_UNSUPPORTED = -5  /* valid request this build does not implement                */
+} dvsg_status;
+
+int dvsg_abi_version(void);
+const char *dvsg_last_error_string(void);
+/* "gfx950" -- the only code object in the library. */
+const char *dvsg_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Thin-plate-spline transformer: ThinPlateSpline.py:4-170, ThinPlateSpline2.py:4-170.
+ * ------------------------------------------------------------------------------------- */
+
+/* `_solve_system` (ThinPlateSpline.py:143-166).  coord [B,P,2]; rhs [B,P,2] is `vector`
+ * when rhs_is_vector != 0 (T solves for coord+vector, ThinPlateSpline.py:161) or `target`
+ * (ThinPlateSpline2.py:160).  T [B,2,P+3].  3 <= P <= 61.  The 28x28 system is assembled in
+ * float32 exactly as the reference does and solved in float64 (partial pivoting), which
+ * lands inside the reference's own float32 LU noise. */
+int dvsg_tps_solve_f32(const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
+                       float *T, void *stream);
+
+/* `_transform` + `_meshgrid` + `_interpolate` fused (ThinPlateSpline.py:30-141): for every
+ * output pixel evaluate [1, x_t, y_t, r_0..r_{P-1}], (x_s, y_s) = T . basis, then sampler A
+ * (coords scaled by W/2, indices clipped BEFORE the weights).  U [B,H,W,C]; coord [B,P,2];
+ * T [B,2,P+3]; out [B,out_h,out_w,C]; x_s, y_s [B*out_h*out_w] (optional).  The [B,P+3,H*W]
+ * basis the reference materialises never exists.  U == NULL && out == NULL: grid only. */
+int dvsg_tps_warp_f32(const float *U, const float *coord, const float *T, int B, int H, int W,
+                      int C, int P, int out_h, int out_w, float *out, float *x_s, float *y_s,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optical-flow warp: warp_with_optical_flow.py:96-176 `tf_warp` (sampler C).
+ * im [B,H,W,C], flow [B,H,W,2] in pixels (dx, dy), out [B,H,W,C].
+ * ------------------------------------------------------------------------------------- */
+int dvsg_flow_warp_f32(const float *im, const float *flow, int B, int H, int W, int C,
+                       float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Spatial transformers: spatial_transformer.py.
+ * ------------------------------------------------------------------------------------- */
+
+/* `bilinear_interp` (spatial_transformer.py:496-563, sampler B) from explicit normalised
+ * coordinates x_s, y_s [B*out_h*out_w]. */
+int dvsg_stn_sample_f32(const float *im, const float *x_s, const float *y_s, int B, int H,
+                        int W, int C, int out_h, int out_w, float *out, void *stream);
+
+/* AffineTransformer._transform (spatial_transformer.py:74-91), theta [B,6]; when im and out
+ * are non-NULL the sampler B gather is fused.  x_s / y_s optional. */
+int dvsg_grid_affine_f32(const float *theta, const float *im, int B, int H, int W, int C,
+                         int out_h, int out_w, float *out, float *x_s, float *y_s, void *stream);
+
+/* ProjectiveTransformer._transform (spatial_transformer.py:423-452), theta [B,8] (the 9th
+ * entry is 1), tf.div_no_nan by z. */
+int dvsg_grid_projective_f32(const float *theta, const float *im, int B, int H, int W, int C,
+                             int out_h, int out_w, float *out, float *x_s, float *y_s,
+                             void *stream);
+
+/* ElasticTransformer constants (spatial_transformer.py:313-362): HOST outputs
+ * source_points [2,n] and L_inv [n,n+3] (= transpose(inverse(L)[:,3:])) for an
+ * grid_size x grid_size control grid, n = grid_size^2 <= 61. */
+int dvsg_elastic_constants_f32(int grid_size, float *source_points_host, float *L_inv_host);
+
+/* ElasticTransformer._transform (spatial_transformer.py:276-296): theta_abs [B,2,n] are the
+ * absolute control point positions (source_points + theta), L_inv [n,n+3] and
+ * source_points [2,n] are DEVICE copies of the constants above.  The
+ * [n+3, H*W] `right_mat` is evaluated on the fly, basis order [x; y; 1; U_0..U_{n-1}]. */
+int dvsg_grid_elastic_f32(const float *theta_abs, const float *L_inv, const float *source_points,
+                          int n, const float *im, int B, int H, int W, int C, int out_h,
+                          int out_w, float *out, float *x_s, float *y_s, void *stream);
+
+/* `scale_RGB` (networks.py:6-16): y = 255 x - mean with the three channel GROUPS reversed.
+ * C must be a multiple of 3. */
+int dvsg_scale_rgb_f32(const float *rgb, int B, int H, int W, int C, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * localizationNet: networks.py:30-46 (slim resnet_v1_50 + 4 dense layers).
+ * ------------------------------------------------------------------------------------- */
+typedef struct dvsg_locnet dvsg_locnet_t;
+
+/* Build the immutable device-side network from HOST arrays named like the reference's
+ * checkpoint (ckpt_manager.py:42; `stabNet/localizationNet/...`, with or without `:0`).
+ * dims is [n_arrays][4] (unused trailing entries ignored), ndims[i] in 1..4.  Unknown names
+ * are ignored; a missing or mis-shaped array is DVSG_ERR_WEIGHTS (the reference silently
+ * runs on random weights instead, ckpt_manager.py:21-22).  BatchNorm (eps 1e-5, moving
+ * statistics) is folded into per-channel scale/shift here.  Allocates device memory. */
+int dvsg_locnet_create(int n_arrays, const char *const *names, const float *const *host_data,
+                       const int *ndims, const int64_t *dims, dvsg_locnet_t **net);
+int dvsg_locnet_destroy(dvsg_locnet_t *net);
+/* input channels of the loaded conv1 (21 for the 7-frame window) */
+int dvsg_locnet_in_channels(const dvsg_locnet_t *net);
+/* bytes of scratch `forward` needs for a [B,H,W,c_in] batch (256-byte aligned). */
+int dvsg_locnet_workspace_bytes(const dvsg_locnet_t *net, int B, int H, int W, size_t *bytes);
+
+/* patches [B,H,W,c_in] in [0,1] -> F_t [B,25,2].  float32 storage, exact-f32 MFMA
+ * (v_mfma_f32_32x32x2_f32) accumulation. */
+int dvsg_locnet_forward_f32(const dvsg_locnet_t *net, const float *patches, int B, int H, int W,
+                            float *F_t, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug / parity tap: run the network up to and including `stage` and copy that stage's
+ * activation (NHWC float32) to act_out.  Stages: 0 conv1, 1 pool1, 2..17 the 16 bottleneck
+ * units in order, 18 pool5 [B,2048].  act_dims receives (h, w, c) on the HOST. */
+int dvsg_locnet_forward_tap_f32(const dvsg_locnet_t *net, const float *patches, int B, int H,
+                                int W, int stage, float *act_out, size_t act_out_bytes,
+                                int *act_dims_host, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* The evaluation graph of model.py:98-123 in one call: F_t = localizationNet(patches_t);
+ * T = solve(V_src, F_t); s_t_pred = TPS warp of u_t.  V_src is the constant 5x5 grid of
+ * model.py:105-110.  s_t_pred [B,H,W,3]; F_t [B,25,2], x_s, y_s [B*H*W] optional. */
+int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B,
+                       int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVSG_AMD_H */

@@ -1,0 +1,78 @@
+"""Oracle (test infrastructure): model.py `StabNet.get_evaluation_model` and the eval.py
+frame loop restated in NumPy float32.  parity unpinned (see oracle/__init__.py).
+
+Reference: model.py:14-25 (ctor), model.py:98-123 (evaluation graph), eval.py:93-124
+(autoregressive clip loop).
+"""
+import collections
+
+import numpy as np
+
+from .networks import localizationNet
+from .thin_plate_spline import ThinPlateSpline as stn
+
+F32 = np.float32
+
+
+def v_src(num_control_points=5):
+    """model.py:105-110: 5x5 grid on [-1,1]^2, x fastest."""
+    lin = np.linspace(-1.0, 1.0, num_control_points)
+    pts = [[x, y] for y in lin for x in lin]
+    return np.array(pts, dtype=F32)
+
+
+class StabNet:
+    def __init__(self, h, w):
+        self.h = h
+        self.w = w
+        self.c = 3
+        self.num_control_points = 5
+        self.param_dim = self.num_control_points ** 2
+
+    def run(self, weights, patches_t, u_t, fetch=("s_t_pred",), taps=None):
+        """Equivalent of ``sess.run([outputs[k] for k in fetch], {patches_t, u_t})`` on the
+        graph of model.py:98-123."""
+        patches_t = np.asarray(patches_t, dtype=F32)
+        u_t = np.asarray(u_t, dtype=F32)
+        B = u_t.shape[0]
+        out = collections.OrderedDict()
+        out["V_src"] = np.tile(v_src(self.num_control_points)[None], (B, 1, 1))     # :111
+        out["num_control_points"] = self.num_control_points
+        out["F_t"] = localizationNet(patches_t, self.param_dim, weights, taps=taps)  # :117
+        if any(k in fetch for k in ("s_t_pred", "x_offset_t", "y_offset_t")):
+            out["s_t_pred"], out["x_offset_t"], out["y_offset_t"] = stn(
+                u_t, out["V_src"], out["F_t"], [self.h, self.w])                    # :120
+        if "s_t_pred_mask" in fetch:
+            out["s_t_pred_mask"], _, _ = stn(
+                np.ones_like(u_t), out["V_src"], out["F_t"], [self.h, self.w])      # :121
+        return [out[k] for k in fetch]
+
+
+def eval_clip(weights, frames, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32)):
+    """eval.py:93-124 on an in-memory clip ``frames`` [N,h,w,3] float (already RGB, /255,
+    resized: eval.py:76-81 is cv2 I/O and out of scope).
+
+    Returns (stabilised [N,h,w,3] float32, side_by_side uint8 [N,h,2w,3]).
+    """
+    skip_length = np.array(skip_length)
+    span = int(skip_length[-1] - skip_length[0])
+    total = [np.asarray(f, dtype=np.float64) for f in frames]        # frame/255. is float64 (eval.py:80)
+    for _ in range(span):
+        total.insert(0, total[0])                                    # :93-94
+    total = np.array(total)
+    net = StabNet(h, w)
+    outs, sbs = [], []
+    sample_idx = skip_length.copy()
+    for frame_idx in range(span, len(total)):                        # :101
+        batch = total[sample_idx]                                    # :103
+        batch = np.expand_dims(np.concatenate(batch, axis=2), 0)     # :104
+        s_t_pred = np.squeeze(net.run(weights, batch.astype(F32), batch[:, :, :, 18:].astype(F32))[0])  # :106-110
+        side = np.uint8(np.concatenate([total[sample_idx[-1]].copy(), s_t_pred], axis=1) * 255.)        # :112
+        total[sample_idx[-1]] = s_t_pred                             # :116
+        if frame_idx == span:                                        # :118-120
+            for i in range(span):
+                total[i] = s_t_pred
+        outs.append(s_t_pred.astype(F32))
+        sbs.append(side)
+        sample_idx = sample_idx + 1                                  # :124
+    return np.stack(outs), np.stack(sbs)

@@ -1,0 +1,251 @@
+"""GPU parity: the HIP warps (through the C ABI, via the reference-shaped facade) against the
+CPU oracle on the same seeded inputs.  Tolerances are stated per test; the reference graph
+is float32 and so are both sides."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import spatial_transformer as ost
+from oracle import thin_plate_spline as otps
+from oracle import warp_with_optical_flow as oflow
+from oracle.networks import scale_RGB as o_scale_RGB
+
+pytestmark = pytest.mark.gpu
+
+# warped-pixel tolerance of BASELINE.json (max abs err vs reference semantics)
+PIX_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from coupe.dvsg_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _grid_err_px(xs, ys, xo, yo, H, W):
+    ex = np.abs(np.asarray(xs, np.float64) - np.asarray(xo, np.float64)).max() * W / 2.0
+    ey = np.abs(np.asarray(ys, np.float64) - np.asarray(yo, np.float64)).max() * H / 2.0
+    return max(ex, ey)
+
+
+# ------------------------------------------------------------------------------- TPS solve
+@pytest.mark.parametrize("P_side", [5, 4, 7])
+def test_tps_solve_matches_oracle(dev, P_side):
+    from coupe.dvsg_amd.ThinPlateSpline import solve_system
+    B = 6
+    lin = np.linspace(-1, 1, P_side)
+    coord = np.tile(np.array([[x, y] for y in lin for x in lin], np.float32)[None], (B, 1, 1))
+    rng = np.random.default_rng(3)
+    coord = coord + (0.02 * rng.standard_normal(coord.shape)).astype(np.float32)  # batch-varying
+    vec = inputs.control_vectors(4, B, P_side * P_side)
+    T = solve_system(coord, vec, True)
+    T64 = otps.solve_system(coord, (coord + vec).astype(np.float32), dtype=np.float64)
+    T32 = otps.solve_system(coord, (coord + vec).astype(np.float32))
+    # float64 solve of the float32-built system: agrees with the exactly rounded answer to
+    # ~1e-5 (the matrix entries themselves carry float32 log rounding, amplified by cond ~4e2)
+    assert np.abs(T - T64).max() < 2e-5
+    # and sits inside the float32-LU noise band of the reference's own tf.matrix_inverse
+    assert np.abs(T - T32).max() < 5e-4
+    T2 = solve_system(coord, (coord + vec).astype(np.float32), False)  # ThinPlateSpline2 mode
+    assert np.abs(T2 - T).max() < 1e-6
+
+
+# ---------------------------------------------------------------- TPS grid + sampler A
+@pytest.mark.parametrize("B,H,W,C", [(2, 72, 128, 3), (1, 37, 53, 3), (2, 40, 300, 1), (1, 33, 65, 5)])
+def test_tps_warp_given_T(dev, B, H, W, C):
+    """Isolates grid generation + sampler A: feed the ORACLE's T through the C ABI."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    U = inputs.smooth_frames(11, B, H, W, C)
+    coord = inputs.v_src(B)
+    vec = inputs.control_vectors(12, B)
+    T = otps.solve_system(coord, (coord + vec).astype(np.float32))
+    xo, yo = otps.source_coords(T, coord, H, W)
+    ref = otps.interpolate_a(U, xo, yo).reshape(B, H, W, C)
+    tU, tc, tT = (torch.from_numpy(a).to(dev) for a in (U, coord, T))
+    out = torch.empty((B, H, W, C), device=dev)
+    xs = torch.empty((B * H * W,), device=dev)
+    ys = torch.empty((B * H * W,), device=dev)
+    _lib.call("dvsg_tps_warp_f32", tU.data_ptr(), tc.data_ptr(), tT.data_ptr(), B, H, W, C, 25, H, W,
+              out.data_ptr(), xs.data_ptr(), ys.data_ptr(), 0)
+    torch.cuda.synchronize()
+    xs, ys, out = xs.cpu().numpy().reshape(B, -1), ys.cpu().numpy().reshape(B, -1), out.cpu().numpy()
+    gerr = _grid_err_px(xs, ys, xo, yo, H, W)
+    assert gerr < 2e-3, "grid error %.3g px" % gerr
+    mask = otps.border_discontinuity_mask(xo, yo, H, W).reshape(B, H, W)
+    err = np.abs(out - ref).max(axis=3)
+    assert err[~mask].max() < PIX_TOL
+    assert mask.mean() < 0.05
+
+
+@pytest.mark.parametrize("out_size", [(72, 128), (36, 64), (50, 90)])
+def test_thin_plate_spline_facade(dev, out_size):
+    """Whole operator (solve + grid + sampler A), reference signature and return order."""
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline, ThinPlateSpline2
+    B, H, W = 2, 72, 128
+    U = inputs.smooth_frames(21, B, H, W)
+    coord = inputs.v_src(B)
+    vec = inputs.control_vectors(22, B)
+    out, x, y = ThinPlateSpline(U, coord, vec, out_size)
+    ro, rx, ry = otps.ThinPlateSpline(U, coord, vec, out_size)
+    assert out.shape == ro.shape and x.shape == rx.shape and y.shape == ry.shape
+    oh, ow = out_size
+    gerr = _grid_err_px(x, y, rx, ry, H, W)
+    assert gerr < 2e-2, "grid error %.3g px" % gerr   # includes the float32 LU noise of the oracle's T
+    mask = otps.border_discontinuity_mask(rx, ry, H, W, delta=3e-2).reshape(B, oh, ow)
+    err = np.abs(out - ro).max(axis=3)
+    assert err[~mask].max() < 3e-3
+    out2, x2, y2 = ThinPlateSpline2(U, coord, (coord + vec).astype(np.float32), out_size)
+    assert np.abs(x2 - x).max() < 1e-6 and np.abs(out2 - out).max() < 1e-5
+
+
+def test_tps_known_answers(dev):
+    """zero vector -> x_s = x_t; uniform vector -> translation."""
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
+    B, H, W = 1, 48, 80
+    U = inputs.smooth_frames(31, B, H, W)
+    coord = inputs.v_src(B)
+    _, x, y = ThinPlateSpline(U, coord, np.zeros_like(coord), (H, W))
+    xt = np.tile(np.linspace(-1, 1, W)[None], (H, 1)).reshape(-1)
+    yt = np.tile(np.linspace(-1, 1, H)[:, None], (1, W)).reshape(-1)
+    assert np.abs(x - xt).max() < 5e-6 and np.abs(y - yt).max() < 5e-6
+    shift = np.zeros_like(coord)
+    shift[..., 0] = 0.125
+    shift[..., 1] = -0.25
+    _, x, y = ThinPlateSpline(U, coord, shift, (H, W))
+    assert np.abs(x - (xt + 0.125)).max() < 5e-6 and np.abs(y - (yt - 0.25)).max() < 5e-6
+
+
+def test_tps_torch_tensors_stay_on_device(dev):
+    import torch
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
+    U = torch.from_numpy(inputs.smooth_frames(41, 1, 32, 48)).to(dev)
+    coord = torch.from_numpy(inputs.v_src(1)).to(dev)
+    out, x, y = ThinPlateSpline(U, coord, torch.zeros_like(coord), (32, 48))
+    assert out.is_cuda and x.is_cuda and y.is_cuda and out.shape == (1, 32, 48, 3)
+
+
+# ----------------------------------------------------------------------- tf_warp (sampler C)
+@pytest.mark.parametrize("B,H,W,C", [(2, 72, 128, 3), (1, 31, 47, 3), (1, 40, 64, 2)])
+def test_tf_warp_matches_oracle(dev, B, H, W, C):
+    from coupe.dvsg_amd.warp_with_optical_flow import tf_warp
+    im = inputs.smooth_frames(51, B, H, W, C)
+    flow = inputs.smooth_flow(52, B, H, W)
+    out = tf_warp(im, flow, H, W)
+    ref = oflow.tf_warp(im, flow, H, W)
+    # every op is a separately rounded float32 op on both sides: expect (near) bit equality
+    assert np.abs(out - ref).max() <= 1e-6
+
+
+def test_tf_warp_known_answers(dev):
+    """SURVEY.md 8c (1)-(3)."""
+    from coupe.dvsg_amd.warp_with_optical_flow import tf_warp
+    B, H, W = 1, 24, 40
+    im = inputs.smooth_frames(61, B, H, W)
+    zero = np.zeros((B, H, W, 2), np.float32)
+    assert np.array_equal(tf_warp(im, zero, H, W), im)
+    f = zero.copy()
+    f[..., 0] = 3.0
+    f[..., 1] = -2.0
+    out = tf_warp(im, f, H, W)
+    exp = np.zeros_like(im)
+    exp[:, 2:, :W - 3] = im[:, :H - 2, 3:]
+    assert np.array_equal(out, exp)
+    f[..., 0] = W + 1.0
+    assert np.array_equal(tf_warp(im, f, H, W), np.zeros_like(im))
+    with pytest.raises(ValueError):
+        tf_warp(im, zero, H - 1, W)
+
+
+# ------------------------------------------------------------- spatial transformers (sampler B)
+def test_bilinear_interp_matches_oracle(dev):
+    from coupe.dvsg_amd.spatial_transformer import bilinear_interp
+    B, H, W, C = 2, 40, 72, 3
+    im = inputs.smooth_frames(71, B, H, W, C)
+    rng = np.random.default_rng(72)
+    oh, ow = 33, 50
+    x = rng.uniform(-1.3, 1.3, B * oh * ow).astype(np.float32)
+    y = rng.uniform(-1.3, 1.3, B * oh * ow).astype(np.float32)
+    out = bilinear_interp(im, x, y, (oh, ow))
+    ref = ost.bilinear_interp(im, x, y, (oh, ow))
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 1e-6
+
+
+def test_affine_transformer(dev):
+    from coupe.dvsg_amd.spatial_transformer import AffineTransformer
+    B, H, W = 3, 40, 72
+    im = inputs.smooth_frames(81, B, H, W)
+    rng = np.random.default_rng(82)
+    theta = (np.array([1, 0, 0, 0, 1, 0], np.float32)[None] + 0.1 * rng.standard_normal((B, 6))).astype(np.float32)
+    out = AffineTransformer((H, W)).transform(im, theta)
+    ref = ost.AffineTransformer((H, W)).transform(im, theta)
+    assert np.abs(out - ref).max() <= 2e-6
+    ident = np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32)[None], (B, 1))
+    out = AffineTransformer((H, W)).transform(im, ident)
+    assert np.abs(out - im).max() < 2e-5   # identity up to 1 ulp of coordinate (W-1 scaling)
+
+
+def test_projective_transformer(dev):
+    from coupe.dvsg_amd.spatial_transformer import ProjectiveTransformer
+    B, H, W, C = 2, 40, 72, 18   # random_mask warps an 18-channel mask (model.py:160-164)
+    im = inputs.smooth_frames(91, B, H, W, C)
+    rng = np.random.default_rng(92)
+    Hm = rng.uniform(-1, 1, (B, 8)) * np.array([0.1, 0.1, 0.5, 0.1, 0.1, 0.5, 0.1, 0.1])
+    Hm = (Hm + np.array([1, 0, 0, 0, 1, 0, 0, 0])).astype(np.float32)
+    t = ProjectiveTransformer((H, W))
+    out = t.transform(im, Hm)
+    o = ost.ProjectiveTransformer((H, W))
+    ref = o.transform(im, Hm)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 5e-5
+    xs, ys = t._transform(im, Hm)
+    rx, ry = o._transform(im, Hm)
+    assert np.abs(xs - rx).max() < 1e-6 and np.abs(ys - ry).max() < 1e-6
+    # tf.div_no_nan: theta = [1,0,0, 0,1,0, 1,0] gives z = x_t + 1, exactly 0 on
+    # the first output column (x_t = -1) -> coordinates 0 there
+    theta = np.tile(np.array([1, 0, 0, 0, 1, 0, 1, 0], np.float32)[None], (B, 1))
+    xs, ys = t._transform(im, theta)
+    rx, ry = o._transform(im, theta)
+    assert np.abs(xs - rx).max() < 1e-6 and np.abs(ys - ry).max() < 1e-6
+    assert np.all(xs.reshape(B, H, W)[:, :, 0] == 0.0) and np.all(ys.reshape(B, H, W)[:, :, 0] == 0.0)
+
+
+@pytest.mark.parametrize("side", [4, 3])
+def test_elastic_transformer(dev, side):
+    from coupe.dvsg_amd.spatial_transformer import ElasticTransformer
+    B, H, W = 2, 40, 72
+    n = side * side
+    im = inputs.smooth_frames(101, B, H, W)
+    rng = np.random.default_rng(102)
+    theta = (0.05 * rng.standard_normal((B, 2 * n))).astype(np.float32)
+    t = ElasticTransformer((H, W), param_dim=2 * n, param_dim_per_side=side)
+    o = ost.ElasticTransformer((H, W), param_dim=2 * n, param_dim_per_side=side)
+    assert np.abs(t.L_inv.cpu().numpy() - o.L_inv).max() < 2e-4      # float64 vs float32 inverse
+    out, xs, ys = t.transform(im, theta)
+    ref, rx, ry = o.transform(im, theta)
+    assert out.shape == ref.shape
+    assert np.abs(xs - rx).max() * W / 2 < 2e-2 and np.abs(ys - ry).max() * H / 2 < 2e-2
+    assert np.abs(out - ref).max() < 3e-3
+    out0, xs0, _ = t.transform(im, np.zeros_like(theta))
+    assert np.abs(out0 - im).max() < 1e-4
+    assert np.abs(t.get_abs_theta(theta) - o.get_abs_theta(theta)).max() < 1e-6
+
+
+def test_scale_rgb(dev):
+    from coupe.dvsg_amd.networks import scale_RGB
+    x = inputs.window_frames(111, 2, 16, 24)
+    assert np.array_equal(scale_RGB(x), o_scale_RGB(x))
+    x3 = inputs.smooth_frames(112, 1, 8, 8, 3)
+    assert np.array_equal(scale_RGB(x3), o_scale_RGB(x3))
+
+
+def test_argument_errors(dev):
+    from coupe.dvsg_amd import DvsgError, _lib
+    with pytest.raises(DvsgError, match="P=2"):
+        _lib.call("dvsg_tps_solve_f32", 8, 8, 1, 1, 2, 8, 0)
+    with pytest.raises(DvsgError, match="NULL"):
+        _lib.call("dvsg_flow_warp_f32", 0, 0, 1, 4, 4, 3, 0, 0)
