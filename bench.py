@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the DVSG hot path on MI355X: stabilised 1280x720 frames per second.
+
+One "step" = one pass of the evaluation graph of model.py:98-123 (localizationNet CNN ->
+TPS solve -> TPS grid + sampler A) over one batch of 16 synthetic 7-frame windows
+(BASELINE.json configs[1]) through `dvsg_stabilize_f32`, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: windows are independent, so each rank stabilises its own batch
+(weak scaling, no data-path collective) and the stabilised frames of every step are gathered
+to rank 0 over RCCL (one `gather` per step, issued asynchronously so that it overlaps the
+next step's kernels; the last one is waited for inside the timed region).
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with hipEvents around every launch
+of the dominant kernel class inside the timed region; `cpu_baseline` times the CPU oracle
+(torch-CPU CNN + NumPy TPS restatement, the "port") on the host cores at N=1.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+PEAK_HBM_GBS = 8000.0
+KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*>", 2: "conv_gemm_kernel<*,1,*>",
+                  3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel"}
+
+
+def gpu_windows(B, H, W, seed, dev, S=7):
+    """Band-limited synthetic windows [B,H,W,3S] in [0,1] generated on the device (same recipe
+    as tests/inputs.py: uniform noise at 1/8 resolution, bicubic upsampling, small shifts)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    lo = torch.rand((B, 3, (H + 16) // 8 + 3, (W + 16) // 8 + 3), generator=g, device=dev)
+    up = F.interpolate(lo, scale_factor=8, mode="bicubic", align_corners=False)[:, :, 8:8 + H + 16, 8:8 + W + 16]
+    up = up.clamp_(0.0, 1.0)
+    shifts = torch.randint(0, 17, (S, 2), generator=g, device=dev).tolist()
+    views = [up[:, :, dy:dy + H, dx:dx + W] for dy, dx in shifts]
+    x = torch.cat(views, dim=1).permute(0, 2, 3, 1).contiguous()
+    return x
+
+
+def cpu_baseline(weights, H, W, budget_s=20.0):
+    """CPU oracle ("port": torch-CPU CNN + NumPy TPS) on one 720p window at a time."""
+    from oracle.cnn_torch import TorchLocNet
+    from oracle.thin_plate_spline import ThinPlateSpline as o_tps
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import inputs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = TorchLocNet(weights)
+    x = inputs.window_frames(1234, 1, H, W)
+    vsrc = inputs.v_src(1)
+    times = []
+    t_start = time.perf_counter()
+    runs = 0
+    while True:
+        t0 = time.perf_counter()
+        Ft = net.forward(x)
+        o_tps(x[..., 18:], vsrc, Ft, (H, W))
+        dt = time.perf_counter() - t0
+        runs += 1
+        if runs > 1:           # first run is warm-up
+            times.append(dt)
+        if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 5:
+            break
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d single-window (B=1, %dx%d) passes of the torch-CPU CNN + NumPy TPS oracle after 1 "
+                      "warm-up; median" % (len(times), W, H)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from coupe.dvsg_amd import _lib
+    from coupe.dvsg_amd.networks import LocNet
+    from coupe.dvsg_amd.weights import make_synthetic_weights
+
+    B, H, W = args.batch, args.height, args.width
+    weights = make_synthetic_weights(seed=0)
+    net = LocNet(weights)
+    patches = gpu_windows(B, H, W, 1234 + rank, dev)
+    u_t = patches[..., 18:].contiguous()
+    outs = [torch.empty((B, H, W, 3), device=dev) for _ in range(2)]
+    F_t = torch.empty((B, 25, 2), device=dev)
+    ws, ws_bytes = net.workspace(B, H, W)
+    stream = torch.cuda.current_stream().cuda_stream
+    gather_bufs = None
+    if dist is not None and not args.no_gather and rank == 0:
+        gather_bufs = [[torch.empty((B, H, W, 3), device=dev) for _ in range(world)] for _ in range(2)]
+
+    def step(i, pending):
+        out = outs[i & 1]
+        _lib.call("dvsg_stabilize_f32", net.handle, patches.data_ptr(), u_t.data_ptr(), B, H, W, out.data_ptr(),
+                  F_t.data_ptr(), 0, 0, ws.data_ptr(), ws_bytes, stream)
+        if dist is not None and not args.no_gather:
+            if pending is not None:
+                pending.wait()   # the buffer pair is reused every second step
+            return dist.gather(out, gather_bufs[i & 1] if rank == 0 else None, dst=0, async_op=True)
+        return None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    pending = None
+    for i in range(args.warmup):
+        pending = step(i, pending)
+    if pending is not None:
+        pending.wait()
+        pending = None
+    fence()
+    if rank == 0:
+        _lib.call("dvsg_prof_begin", args.prof_class)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pending = step(i, pending)
+    if pending is not None:
+        pending.wait()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if rank == 0:
+        ms, n, fl, by = ctypes.c_double(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        _lib.call("dvsg_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+        prof = (ms.value, n.value, fl.value, by.value)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * B * args.steps
+        ms_per_step = 1e3 * elapsed / args.steps
+        total_ms, launches, flops, nbytes = prof
+        cls = args.prof_class
+        if cls <= 2:
+            achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_F32_MFMA_TFLOPS}
+        else:
+            achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBS}
+        roofline.update({"traffic": None, "kernel": KERNEL_CLASSES[cls], "launches": launches,
+                         "avg_launch_ms": total_ms / max(launches, 1),
+                         "algorithmic_per_launch": (flops if cls <= 2 else nbytes) / max(launches, 1)})
+        line = {
+            "metric": "stabilized frames/sec (1280x720 RGB)", "value": frames / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU"
+                                   % (B, W, H),
+                       "batch_per_gpu": B, "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
+                       "gather": bool(dist is not None and not args.no_gather),
+                       "weights": "synthetic seed 0 (reference ships no checkpoint)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, H, W)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

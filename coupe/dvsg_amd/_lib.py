@@ -36,6 +36,9 @@ SIGNATURES = {
     "dvsg_locnet_forward_tap_f32": [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t,
                                     ctypes.POINTER(_i), _vp, ctypes.c_size_t, _vp],
     "dvsg_stabilize_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_prof_begin": [_i],
+    "dvsg_prof_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double),
+                      ctypes.POINTER(ctypes.c_double)],
 }
 QUERIES = ("dvsg_abi_version", "dvsg_last_error_string", "dvsg_target_arch")
 

@@ -23,3 +23,69 @@ int dvsg_abi_version(void) { return DVSG_ABI_VERSION; }
 const char *dvsg_last_error_string(void) { return dvsg::error_buffer(); }
 const char *dvsg_target_arch(void) { return "gfx950"; }
 }
+
+// ---- per-kernel-class timing -------------------------------------------------------------
+#include <vector>
+namespace dvsg {
+namespace {
+struct Prof {
+  int cls = -1;
+  std::vector<hipEvent_t> start, stop;
+  double flops = 0, bytes = 0;
+} g_prof;
+}  // namespace
+
+ProfScope::ProfScope(int cls, hipStream_t s, double flops, double bytes) : idx_(-1), s_(s) {
+  if (cls != g_prof.cls) return;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  if (hipEventCreate(&b) != hipSuccess) {
+    (void)hipEventDestroy(a);
+    return;
+  }
+  g_prof.start.push_back(a);
+  g_prof.stop.push_back(b);
+  g_prof.flops += flops;
+  g_prof.bytes += bytes;
+  idx_ = (int)g_prof.start.size() - 1;
+  (void)hipEventRecord(a, s);
+}
+ProfScope::~ProfScope() {
+  if (idx_ >= 0) (void)hipEventRecord(g_prof.stop[idx_], s_);
+}
+}  // namespace dvsg
+
+extern "C" {
+int dvsg_prof_begin(int kernel_class) {
+  DVSG_REQUIRE(kernel_class >= 0 && kernel_class < dvsg::kNumCls, "dvsg_prof_begin: class %d outside [0,%d)",
+               kernel_class, dvsg::kNumCls);
+  DVSG_REQUIRE(dvsg::g_prof.cls < 0, "dvsg_prof_begin: profiling already armed");
+  dvsg::g_prof.cls = kernel_class;
+  dvsg::g_prof.flops = dvsg::g_prof.bytes = 0;
+  return DVSG_OK;
+}
+
+int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes) {
+  using dvsg::g_prof;
+  DVSG_REQUIRE(g_prof.cls >= 0, "dvsg_prof_end: profiling not armed");
+  double ms = 0;
+  int rc = DVSG_OK;
+  for (size_t i = 0; i < g_prof.start.size(); ++i) {
+    float t = 0;
+    if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess ||
+        hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]) != hipSuccess)
+      rc = dvsg::fail(DVSG_ERR_HIP, "dvsg_prof_end: event query failed");
+    ms += t;
+    (void)hipEventDestroy(g_prof.start[i]);
+    (void)hipEventDestroy(g_prof.stop[i]);
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = (int)g_prof.start.size();
+  if (flops) *flops = g_prof.flops;
+  if (bytes) *bytes = g_prof.bytes;
+  g_prof.start.clear();
+  g_prof.stop.clear();
+  g_prof.cls = -1;
+  return rc;
+}
+}

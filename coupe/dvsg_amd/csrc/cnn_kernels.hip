@@ -486,6 +486,10 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   d.K = p.ksize * p.ksize * p.Cin;
   d.mtiles = (int)((M + BM - 1) / BM);
   const int res = !p.res ? 0 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
+  // algorithmic work: 2 M N K flops; bytes = input + weights + output (+ residual) once each
+  ProfScope prof(p.ksize == 3 ? kClsConv3x3 : kClsConv1x1, s, 2.0 * (double)M * p.Cout * d.K,
+                 4.0 * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * d.K +
+                        (double)M * p.Cout * (p.res ? 2.0 : 1.0)));
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide.
   const bool wide = p.Cout % 128 == 0 && (long)d.mtiles * (p.Cout / 128) >= 512;
   if (wide) {
@@ -503,6 +507,8 @@ int launch_conv1(const float *x, const float *wt1, const float *bias, float *y, 
   const int wtiles = ceil_div(Wo, C1_TILE);
   const long blocks = (long)wtiles * Ho * B;
   DVSG_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv1: grid of %ld workgroups out of range", blocks);
+  ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
+                 4.0 * ((double)B * H * W * kConv1Cin + (double)B * Ho * Wo * 64));
   hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, wt1, bias, y, H, W, Ho, Wo,
                      wtiles);
   return check_launch("conv1_kernel");
@@ -514,12 +520,14 @@ int launch_maxpool(const float *x, float *y, int B, int H, int W, int C, int Ho,
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
   const size_t want = (total + 255) / 256;
   const int blocks = (int)(want < 16384 ? want : 16384);
+  ProfScope prof(kClsMaxpool, s, 0.0, 4.0 * C * ((double)B * H * W + (double)B * Ho * Wo));
   hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, C / 4, Ho, Wo, pad_top,
                      pad_left, total);
   return check_launch("maxpool_kernel");
 }
 
 int launch_avgpool_partial(const float *x, float *part, int B, int HW, int C, hipStream_t s) {
+  ProfScope prof(kClsHead, s, 0.0, 4.0 * (double)B * HW * C);
   hipLaunchKernelGGL(avgpool_partial_kernel, dim3(ceil_div(C, 256), B, kPoolSplits), dim3(256), 0, s, x,
                      part, B, HW, C);
   return check_launch("avgpool_partial_kernel");
@@ -529,6 +537,7 @@ int launch_dense(const float *xin, int s_in, const float *bias_in, float scale_i
                  const float *W, float *out_part, int B, int K, int N, hipStream_t s) {
   DVSG_REQUIRE(B >= 1 && B <= kDenseMaxB, "dense: B=%d outside [1,%d]", B, kDenseMaxB);
   DVSG_REQUIRE(K % kDenseSplits == 0, "dense: K=%d must be a multiple of %d", K, kDenseSplits);
+  ProfScope prof(kClsHead, s, 2.0 * B * (double)K * N, 4.0 * (double)K * N);
   hipLaunchKernelGGL(dense_kernel, dim3(ceil_div(N, 64), kDenseSplits), dim3(256), 0, s, xin, s_in, bias_in,
                      scale_in, lrelu_in, W, out_part, B, K, N);
   return check_launch("dense_kernel");

@@ -45,3 +45,26 @@ int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dvsg
+
+// ---- optional per-kernel-class timing (bench.py roofline leg; see dvsg_prof_begin) ----------
+namespace dvsg {
+enum KernelClass {
+  kClsConv1 = 0,   // conv1_kernel (7x7/2 + scale_RGB)
+  kClsConv3x3 = 1, // conv_gemm_kernel<*,3,..>
+  kClsConv1x1 = 2, // conv_gemm_kernel<*,1,..>
+  kClsMaxpool = 3,
+  kClsHead = 4,    // avgpool + dense
+  kClsTpsSolve = 5,
+  kClsTpsWarp = 6,
+  kClsStn = 7,     // flow / sampler B / affine / projective / elastic
+  kNumCls = 8
+};
+// RAII: when profiling is armed for `cls`, brackets the launches issued in its lifetime with a
+// hipEvent pair on `s` and books their algorithmic FLOPs / bytes.  Otherwise a no-op.
+struct ProfScope {
+  ProfScope(int cls, hipStream_t s, double flops, double bytes);
+  ~ProfScope();
+  int idx_;
+  hipStream_t s_;
+};
+}  // namespace dvsg

@@ -420,6 +420,11 @@ template <int SRC>
 int launch_stn(StnParams p, int B, hipStream_t s, const char *what) {
   constexpr int PPT = 2;
   dim3 grid(ceil_div(p.out_w, kThreads), ceil_div(p.out_h, PPT), B);
+  // algorithmic bytes per output pixel: read C + write C floats (+ flow 8 B / coords 8 B)
+  const double px = (double)B * p.out_h * p.out_w;
+  ProfScope prof(kClsStn, s, 0.0,
+                 px * (p.im ? 8.0 * p.Cn : 0.0) + px * ((SRC == kFlow || SRC == kCoords) ? 8.0 : 0.0) +
+                     px * ((p.xs_out ? 4.0 : 0.0) + (p.ys_out ? 4.0 : 0.0)));
   if (p.Cn == 3)
     hipLaunchKernelGGL((stn_kernel<SRC, 3, PPT>), grid, dim3(kThreads), 0, s, p);
   else if (p.Cn == 1)
@@ -447,6 +452,7 @@ int tps_solve_impl(const float *coord, long coord_bstride, const float *rhs, int
   DVSG_REQUIRE(coord && rhs && T, "dvsg_tps_solve_f32: NULL pointer");
   DVSG_REQUIRE(B > 0, "dvsg_tps_solve_f32: B=%d must be positive", B);
   DVSG_REQUIRE(P >= 3 && P <= kMaxPts, "dvsg_tps_solve_f32: P=%d outside [3,%d]", P, kMaxPts);
+  ProfScope prof(kClsTpsSolve, as_stream(stream), 0.0, (double)B * (4.0 * P + 2.0 * (P + 3)) * 4.0);
   hipLaunchKernelGGL(tps_solve_kernel, dim3(B), dim3(64), 0, as_stream(stream), coord, coord_bstride, rhs,
                      rhs_is_vector, P, T);
   return check_launch("tps_solve_kernel");
@@ -464,6 +470,10 @@ int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const 
   dim3 grid(ceil_div(out_w, kThreads), ceil_div(out_h, PPT), B);
   const float sx = lin_step(out_w), sy = lin_step(out_h);
   hipStream_t s = as_stream(stream);
+  // algorithmic bytes: read U once (C floats per input pixel) + write out (+ x_s, y_s when asked)
+  ProfScope prof(kClsTpsWarp, s, 0.0,
+                 (U ? 4.0 * C * ((double)B * H * W + (double)B * out_h * out_w) : 0.0) +
+                     (double)B * out_h * out_w * ((x_s ? 4.0 : 0.0) + (y_s ? 4.0 : 0.0)));
   if (!U) C = 3;
   if (C == 3)
     hipLaunchKernelGGL((tps_warp_kernel<3, PPT>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,

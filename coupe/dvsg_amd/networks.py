@@ -84,7 +84,7 @@ class LocNet(object):
         B, H, W, C = t.shape
         ws, nbytes = self.workspace(B, H, W)
         h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        cap = B * h1 * w1 * 64
+        cap = B * max(h1 * w1 * 64, ((h1 + 1) // 2) * ((w1 + 1) // 2) * 256)
         buf = empty((cap,), t)
         dims = (ctypes.c_int * 3)()
         _lib.call("dvsg_locnet_forward_tap_f32", self.handle, ptr(t), B, H, W, int(stage), ptr(buf), cap * 4,

@@ -151,6 +151,18 @@ int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const f
                        int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Measurement hook (bench.py's roofline leg; not part of the reference surface).  While
+ * armed for one kernel class, every launch of that class made by this library is bracketed
+ * by a hipEvent pair on the launch stream.  dvsg_prof_end synchronises on those events and
+ * returns the summed durations, the launch count and the algorithmic FLOPs / bytes of those
+ * launches.  Classes: 0 conv1 (7x7/2 + scale_RGB), 1 conv 3x3, 2 conv 1x1, 3 max pool,
+ * 4 head (avg pool + dense), 5 TPS solve, 6 TPS grid + sampler A, 7 flow / STN samplers.
+ * Process-global and not thread-safe: arm it only around single-threaded benchmark code.
+ * ------------------------------------------------------------------------------------- */
+int dvsg_prof_begin(int kernel_class);
+int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif
