@@ -50,13 +50,30 @@ def gpu_windows(B, H, W, seed, dev, S=7):
     return x
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity, cgroup quota), and never more
+    than the 16-core share a one-GPU box grants (oversubscribing torch-CPU is slower)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("DVSG_BENCH_CPU_THREADS", "16")))
+
+
 def cpu_baseline(weights, H, W, budget_s=20.0):
     """CPU oracle ("port": torch-CPU CNN + NumPy TPS) on one 720p window at a time."""
     from oracle.cnn_torch import TorchLocNet
     from oracle.thin_plate_spline import ThinPlateSpline as o_tps
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import inputs
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     net = TorchLocNet(weights)
     x = inputs.window_frames(1234, 1, H, W)

@@ -1,0 +1,104 @@
+"""No-GPU checks of the C-ABI boundary: the shared library loads, exports every symbol that
+include/dvsg_amd.h declares, rejects bad arguments with a status code (never aborts), and its
+host-only entry point agrees with the oracle.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dvsg_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dvsg_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from coupe.dvsg_amd import _lib
+    return _lib.load()
+
+
+def test_header_declares_the_survey_export_set():
+    syms = declared_symbols()
+    for s in ["dvsg_tps_solve_f32", "dvsg_tps_warp_f32", "dvsg_flow_warp_f32", "dvsg_stn_sample_f32",
+              "dvsg_grid_projective_f32", "dvsg_grid_affine_f32", "dvsg_grid_elastic_f32", "dvsg_locnet_create",
+              "dvsg_locnet_destroy", "dvsg_locnet_forward_f32", "dvsg_stabilize_f32", "dvsg_last_error_string"]:
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for s in declared_symbols():
+        assert hasattr(lib, s), "libdvsg_amd.so does not export %s" % s
+    assert lib.dvsg_abi_version() == 1
+    assert lib.dvsg_target_arch() == b"gfx950"
+
+
+def test_python_binding_covers_every_declared_symbol():
+    from coupe.dvsg_amd import _lib
+    bound = set(_lib.SIGNATURES) | set(_lib.QUERIES)
+    assert set(declared_symbols()) == bound
+
+
+def test_bad_arguments_return_status_not_abort(lib):
+    from coupe.dvsg_amd import DvsgError, _lib
+    assert lib.dvsg_tps_solve_f32(None, None, 1, 1, 25, None, None) == -1
+    assert b"NULL" in lib.dvsg_last_error_string()
+    assert lib.dvsg_tps_solve_f32(8, 8, 1, 1, 99, 8, None) == -1
+    assert b"P=99" in lib.dvsg_last_error_string()
+    assert lib.dvsg_flow_warp_f32(8, 8, 0, 4, 4, 3, 8, None) == -1
+    assert lib.dvsg_scale_rgb_f32(8, 1, 4, 4, 4, 8, None) == -1          # C not a multiple of 3
+    assert lib.dvsg_grid_elastic_f32(8, 8, 8, 100, None, 1, 4, 4, 3, 4, 4, None, 8, 8, None) == -1
+    assert lib.dvsg_prof_end(None, None, None, None) == -1               # not armed
+    with pytest.raises(DvsgError, match="dvsg_locnet_workspace_bytes"):
+        _lib.call("dvsg_locnet_workspace_bytes", None, 1, 8, 8, None)
+
+
+def test_locnet_create_rejects_incomplete_checkpoint(lib):
+    """Runs before any device work: a missing array is DVSG_ERR_WEIGHTS (-4)."""
+    name = (ctypes.c_char_p * 1)(b"stabNet/localizationNet/df/dense1/b:0")
+    arr = np.zeros(2048, np.float32)
+    data = (ctypes.c_void_p * 1)(arr.ctypes.data)
+    nd = (ctypes.c_int * 1)(1)
+    dims = (ctypes.c_int64 * 4)(2048, 1, 1, 1)
+    handle = ctypes.c_void_p()
+    rc = lib.dvsg_locnet_create(1, name, data, nd, dims, ctypes.byref(handle))
+    assert rc == -4 and b"conv1/weights" in lib.dvsg_last_error_string()
+    assert not handle.value
+
+
+@pytest.mark.parametrize("g", [4, 3, 5])
+def test_elastic_constants_match_oracle(lib, g):
+    from oracle.spatial_transformer import ElasticTransformer
+    n = g * g
+    src = np.empty((2, n), np.float32)
+    linv = np.empty((n, n + 3), np.float32)
+    assert lib.dvsg_elastic_constants_f32(g, src.ctypes.data, linv.ctypes.data) == 0
+    o = ElasticTransformer((8, 8), param_dim=2 * n, param_dim_per_side=g)
+    assert np.array_equal(src, o.source_points)
+    assert np.abs(linv - o.L_inv).max() < 5e-4     # float64 vs float32 (LAPACK) inverse
+
+
+def test_no_cpu_fallback_without_device():
+    """The product must fail loudly, not compute on the CPU, when no HIP device is visible."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from coupe.dvsg_amd import DvsgError
+    from coupe.dvsg_amd.warp_with_optical_flow import tf_warp
+    with pytest.raises(DvsgError, match="no CPU fallback"):
+        tf_warp(np.zeros((1, 4, 4, 3), np.float32), np.zeros((1, 4, 4, 2), np.float32), 4, 4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "coupe")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f

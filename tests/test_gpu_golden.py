@@ -1,0 +1,67 @@
+"""GPU parity against the committed golden vectors (tests/golden/*.npz) and the eval.py clip
+loop (device-resident history) against the oracle's restatement of it."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+from oracle import model as omodel
+from oracle.thin_plate_spline import border_discontinuity_mask
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with np.load(os.path.join(GOLD, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_warps_against_golden():
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
+    from coupe.dvsg_amd.spatial_transformer import AffineTransformer, ElasticTransformer, ProjectiveTransformer
+    from coupe.dvsg_amd.warp_with_optical_flow import tf_warp
+    g = _load("warps.npz")
+    B, H, W = 2, 32, 48
+    U = inputs.smooth_frames(1001, B, H, W)
+    out, xs, ys = ThinPlateSpline(U, inputs.v_src(B), inputs.control_vectors(1002, B), (H, W))
+    assert max(np.abs(xs - g["tps_xs"]).max() * W / 2, np.abs(ys - g["tps_ys"]).max() * H / 2) < 2e-2
+    mask = border_discontinuity_mask(g["tps_xs"], g["tps_ys"], H, W, delta=3e-2).reshape(B, H, W)
+    assert np.abs(out - g["tps_out"]).max(axis=3)[~mask].max() < 3e-3
+    assert np.abs(tf_warp(U, inputs.smooth_flow(1003, B, H, W), H, W) - g["flow_out"]).max() <= 1e-6
+    assert np.abs(AffineTransformer((H, W)).transform(U, g["theta_affine"]) - g["affine_out"]).max() <= 2e-6
+    assert np.abs(ProjectiveTransformer((H, W)).transform(U, g["theta_projective"]) - g["projective_out"]).max() <= 5e-5
+    eo, ex, ey = ElasticTransformer((H, W)).transform(U, g["theta_elastic"])
+    assert np.abs(eo - g["elastic_out"]).max() < 3e-3
+
+
+def test_locnet_against_golden(synthetic_weights):
+    from coupe.dvsg_amd.networks import LocNet
+    g = _load("locnet.npz")
+    x = inputs.window_frames(2001, 2, 64, 96)
+    net = LocNet(synthetic_weights)
+    assert np.abs(net.forward(x).cpu().numpy() - g["F_t"]).max() <= 1e-5
+    pool5 = net.tap(x, 18).cpu().numpy().reshape(2, 2048)
+    assert np.abs(pool5 - g["pool5"]).max() <= 2e-5 * np.abs(g["pool5"]).max()
+
+
+def test_eval_clip_loop(synthetic_weights):
+    """eval.py:93-124 with the history on the device: same stabilised sequence as the oracle
+    (the recurrence feeds each output back, so errors compound over the steps)."""
+    from coupe.dvsg_amd.clip import stabilize_clip
+    from coupe.dvsg_amd.model import Session, StabNet
+    g = _load("clip.npz")
+    H, W = 32, 48
+    frames = inputs.smooth_frames(3001, 3, H, W)
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    model.get_evaluation_model(7)
+    out, side = stabilize_clip(model, Session(), frames, side_by_side=True)
+    assert out.shape == (3, H, W, 3) and side.shape == (3, H, 2 * W, 3) and side.dtype == np.uint8
+    ref, rside = omodel.eval_clip(synthetic_weights, frames, H, W)
+    assert np.abs(out - ref).max() < 2e-2             # border-discontinuity pixels included
+    assert np.median(np.abs(out - ref)) < 1e-5
+    assert np.abs(out - g["stabilised"]).max() < 2e-2
+    assert np.array_equal(side[:, :, :W], rside[:, :, :W])      # left half: the unstable input
+    diff = np.abs(side[:, :, W:].astype(int) - rside[:, :, W:].astype(int))
+    assert (diff > 1).mean() < 0.01

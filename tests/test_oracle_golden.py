@@ -1,0 +1,59 @@
+"""The committed golden vectors (tests/golden/*.npz, written by tests/golden/make_golden.py
+from the oracle) must be reproduced by the oracle on any machine: pins the oracle against
+drift and checks the eval.py harness restatement."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs
+from oracle import model as omodel
+from oracle import networks as onet
+from oracle import spatial_transformer as ost
+from oracle import thin_plate_spline as otps
+from oracle import warp_with_optical_flow as oflow
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with np.load(os.path.join(GOLD, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_warps_golden():
+    g = _load("warps.npz")
+    B, H, W = 2, 32, 48
+    U = inputs.smooth_frames(1001, B, H, W)
+    coord, vec = inputs.v_src(B), inputs.control_vectors(1002, B)
+    out, xs, ys = otps.ThinPlateSpline(U, coord, vec, (H, W))
+    # LAPACK's float32 inverse may differ across builds by its own rounding noise
+    assert np.abs(xs - g["tps_xs"]).max() < 2e-5 and np.abs(ys - g["tps_ys"]).max() < 2e-5
+    mask = otps.border_discontinuity_mask(g["tps_xs"], g["tps_ys"], H, W, delta=3e-2).reshape(B, H, W)
+    assert np.abs(out - g["tps_out"]).max(axis=3)[~mask].max() < 1e-3
+    assert np.array_equal(oflow.tf_warp(U, inputs.smooth_flow(1003, B, H, W), H, W), g["flow_out"])
+    assert np.abs(ost.AffineTransformer((H, W)).transform(U, g["theta_affine"]) - g["affine_out"]).max() < 1e-6
+    assert np.abs(ost.ProjectiveTransformer((H, W)).transform(U, g["theta_projective"])
+                  - g["projective_out"]).max() < 1e-5
+    eo, ex, ey = ost.ElasticTransformer((H, W)).transform(U, g["theta_elastic"])
+    assert np.abs(ex - g["elastic_xs"]).max() < 2e-5 and np.abs(eo - g["elastic_out"]).max() < 1e-3
+
+
+def test_locnet_golden(synthetic_weights):
+    g = _load("locnet.npz")
+    x = inputs.window_frames(2001, 2, 64, 96)
+    taps = {}
+    F = onet.localizationNet(x, 25, synthetic_weights, taps=taps)
+    assert np.abs(F - g["F_t"]).max() < 5e-6
+    assert np.abs(taps["pool5"] - g["pool5"]).max() < 1e-4 * np.abs(g["pool5"]).max()
+
+
+def test_clip_golden(synthetic_weights):
+    g = _load("clip.npz")
+    frames = inputs.smooth_frames(3001, 3, 32, 48)
+    outs, side = omodel.eval_clip(synthetic_weights, frames, 32, 48)
+    assert outs.shape == g["stabilised"].shape == (3, 32, 48, 3)
+    assert side.shape == (3, 32, 96, 3) and side.dtype == np.uint8
+    assert np.abs(outs - g["stabilised"]).max() < 5e-3
+    # left half of the side-by-side is the (unstabilised) input frame, truncating cast
+    assert np.array_equal(side[0, :, :48], np.uint8(frames[0].astype(np.float64) * 255.))
