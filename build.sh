@@ -8,11 +8,14 @@ OBJ=build/obj
 mkdir -p "$OBJ"
 COMMON="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $*"
 pids=()
-# warps: separately rounded float32 ops like the reference graph (see warp_kernels.hip)
+# warps and conv1's fused scale_RGB: separately rounded float32 ops like the reference graph
 hipcc $COMMON -ffp-contract=off -c $SRC/warp_kernels.hip -o $OBJ/warp_kernels.o & pids+=($!)
-hipcc $COMMON -c $SRC/cnn_kernels.hip -o $OBJ/cnn_kernels.o & pids+=($!)
+hipcc $COMMON -ffp-contract=off -c $SRC/conv1_pool.hip -o $OBJ/conv1_pool.o & pids+=($!)
+hipcc $COMMON -c $SRC/conv_gemm.hip -o $OBJ/conv_gemm.o & pids+=($!)
+hipcc $COMMON -c $SRC/head.hip -o $OBJ/head.o & pids+=($!)
 hipcc $COMMON -c $SRC/locnet.hip -o $OBJ/locnet.o & pids+=($!)
 hipcc $COMMON -x hip -c $SRC/api_common.cpp -o $OBJ/api_common.o & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/warp_kernels.o $OBJ/cnn_kernels.o $OBJ/locnet.o $OBJ/api_common.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/warp_kernels.o $OBJ/conv1_pool.o $OBJ/conv_gemm.o \
+  $OBJ/head.o $OBJ/locnet.o $OBJ/api_common.o
 echo "built $OUT"

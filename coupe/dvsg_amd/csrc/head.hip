@@ -1,0 +1,118 @@
+// Head of localizationNet: global average pool (slim `reduce_mean([1,2])`) + the four
+// tensorlayer DenseLayers 2048 -> 2048 -> 1024 -> 512 -> 50 with leaky-ReLU 0.2
+// (networks.py:31,36-44).  Tiny (6.8 MMAC per frame) and latency-bound: every stage writes
+// deterministic split partial sums and the next stage folds "sum the partials, add bias,
+// leaky-ReLU" into its operand load -- no atomics, bitwise reproducible.
+#include "cnn_kernels.h"
+
+namespace dvsg {
+namespace {
+
+__global__ __launch_bounds__(256) void avgpool_partial_kernel(const float *__restrict__ x,
+                                                             float *__restrict__ part, int B, int HW,
+                                                             int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, s = blockIdx.z;
+  if (c >= C) return;
+  const int per = (HW + kPoolSplits - 1) / kPoolSplits;
+  const int i0 = s * per, i1 = min(HW, i0 + per);
+  const float *px = x + ((size_t)b * HW) * C + c;
+  float acc = 0.f;
+  for (int i = i0; i < i1; ++i) acc += px[(size_t)i * C];
+  part[((size_t)b * kPoolSplits + s) * C + c] = acc;
+}
+
+constexpr int kDenseMaxB = 16;
+constexpr int kDenseKC = 256;
+
+// out_part[b][ks][n] = sum_{k in slice ks} f(x)[b][k] * W[k][n],
+// f(x)[b][k] = act( scale_in * sum_s xin[b][s][k] + bias_in[k] ).
+__global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ xin, int s_in,
+                                                   const float *__restrict__ bias_in, float scale_in,
+                                                   int lrelu_in, const float *__restrict__ Wm,
+                                                   float *__restrict__ out_part, int B, int K, int N) {
+  __shared__ float xs[kDenseMaxB][kDenseKC];
+  __shared__ float red[4][kDenseMaxB][64];
+  const int tid = threadIdx.x;
+  const int col = blockIdx.x * 64 + (tid & 63);
+  const int kg = tid >> 6;
+  const int ks = blockIdx.y;
+  const int kper = K / kDenseSplits;
+  float acc[kDenseMaxB];
+#pragma unroll
+  for (int b = 0; b < kDenseMaxB; ++b) acc[b] = 0.f;
+  for (int kc = 0; kc < kper; kc += kDenseKC) {
+    const int kbase = ks * kper + kc;
+    const int kn = min(kDenseKC, kper - kc);
+    __syncthreads();
+    for (int e = tid; e < kDenseMaxB * kDenseKC; e += 256) {
+      const int b = e / kDenseKC, k = e % kDenseKC;
+      float v = 0.f;
+      if (b < B && k < kn) {
+        for (int s = 0; s < s_in; ++s) v += xin[((size_t)b * s_in + s) * K + kbase + k];
+        v *= scale_in;
+        if (bias_in) v += bias_in[kbase + k];
+        if (lrelu_in) v = v >= 0.f ? v : 0.2f * v;  // networks.py:31
+      }
+      xs[b][k] = v;
+    }
+    __syncthreads();
+    if (col < N) {
+      for (int k = kg; k < kn; k += 4) {
+        const float w = Wm[(size_t)(kbase + k) * N + col];
+#pragma unroll
+        for (int b = 0; b < kDenseMaxB; ++b) acc[b] = fmaf(xs[b][k], w, acc[b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < kDenseMaxB; ++b) red[kg][b][tid & 63] = acc[b];
+  __syncthreads();
+  for (int e = tid; e < kDenseMaxB * 64; e += 256) {
+    const int b = e >> 6, c = e & 63;
+    const int n = blockIdx.x * 64 + c;
+    if (b < B && n < N)
+      out_part[((size_t)b * kDenseSplits + ks) * N + n] =
+          (red[0][b][c] + red[1][b][c]) + (red[2][b][c] + red[3][b][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_finalize_kernel(const float *__restrict__ part, int s_in,
+                                                            float scale, const float *__restrict__ bias,
+                                                            float *__restrict__ out, int B, int N) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * N) return;
+  const int b = e / N, n = e % N;
+  float v = 0.f;
+  for (int s = 0; s < s_in; ++s) v += part[((size_t)b * s_in + s) * N + n];
+  v *= scale;
+  out[e] = bias ? v + bias[n] : v;
+}
+
+}  // namespace
+
+int launch_avgpool_partial(const float *x, float *part, int B, int HW, int C, hipStream_t s) {
+  ProfScope prof(kClsHead, s, 0.0, 4.0 * (double)B * HW * C);
+  hipLaunchKernelGGL(avgpool_partial_kernel, dim3(ceil_div(C, 256), B, kPoolSplits), dim3(256), 0, s, x,
+                     part, B, HW, C);
+  return check_launch("avgpool_partial_kernel");
+}
+
+int launch_dense(const float *xin, int s_in, const float *bias_in, float scale_in, int lrelu_in,
+                 const float *W, float *out_part, int B, int K, int N, hipStream_t s) {
+  DVSG_REQUIRE(B >= 1 && B <= kDenseMaxB, "dense: B=%d outside [1,%d]", B, kDenseMaxB);
+  DVSG_REQUIRE(K % kDenseSplits == 0, "dense: K=%d must be a multiple of %d", K, kDenseSplits);
+  ProfScope prof(kClsHead, s, 2.0 * B * (double)K * N, 4.0 * (double)K * N);
+  hipLaunchKernelGGL(dense_kernel, dim3(ceil_div(N, 64), kDenseSplits), dim3(256), 0, s, xin, s_in, bias_in,
+                     scale_in, lrelu_in, W, out_part, B, K, N);
+  return check_launch("dense_kernel");
+}
+
+int launch_dense_finalize(const float *part, int s_in, float scale, const float *bias, float *out, int B,
+                          int N, hipStream_t s) {
+  hipLaunchKernelGGL(dense_finalize_kernel, dim3(ceil_div((long)B * N, 256)), dim3(256), 0, s, part, s_in,
+                     scale, bias, out, B, N);
+  return check_launch("dense_finalize_kernel");
+}
+
+}  // namespace dvsg

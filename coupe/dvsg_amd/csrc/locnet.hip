@@ -404,6 +404,31 @@ int dvsg_locnet_forward_tap_f32(const dvsg_locnet_t *net, const float *patches, 
                  workspace_bytes, as_stream(stream));
 }
 
+int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y, int B, int H,
+                       int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
+  DVSG_REQUIRE(x && wt && bias && y, "dvsg_conv_gemm_f32: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && res_stride >= 1, "dvsg_conv_gemm_f32: bad shape");
+  ConvGemm p;
+  p.x = x; p.wt = wt; p.bias = bias; p.res = res; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = ksize == 3 ? 1 : 0;
+  p.res_H = p.Ho * res_stride - (res_stride - 1); p.res_W = p.Wo * res_stride - (res_stride - 1);
+  p.res_stride = res_stride;
+  if (res && res_stride == 1) { p.res_H = p.Ho; p.res_W = p.Wo; }
+  p.relu = relu;
+  return launch_conv_gemm(p, as_stream(stream));
+}
+
+int dvsg_debug_set_option(const char *name, int value) {
+  DVSG_REQUIRE(name, "dvsg_debug_set_option: NULL name");
+  if (std::strcmp(name, "conv_variant") == 0) {
+    set_conv_variant(value);
+    return DVSG_OK;
+  }
+  return fail(DVSG_ERR_INVALID_ARG, "dvsg_debug_set_option: unknown option %s", name);
+}
+
 int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                        void *stream) {

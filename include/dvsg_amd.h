@@ -151,6 +151,19 @@ int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const f
                        int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* Building block of localizationNet, exposed for layer-level parity tests and micro-benchmarks:
+ * slim conv2d (1x1, or 3x3 with pad 1 = conv2d_same) + folded BatchNorm + optional residual +
+ * optional ReLU as one implicit-GEMM launch.  x [B,H,W,Cin]; wt [Cout][ksize*ksize*Cin] (k order
+ * kh, kw, c; BatchNorm scale already folded in); bias [Cout]; res (optional) is sampled at
+ * (ho*res_stride, wo*res_stride) of a [B, (Ho-1)*res_stride+1, (Wo-1)*res_stride+1, Cout] tensor;
+ * y [B,Ho,Wo,Cout] with Ho = (H-1)/stride+1.  Cin % 32 == 0, Cout % 64 == 0. */
+int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y,
+                       int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                       int res_stride, void *stream);
+
+/* Diagnostic A/B switches for kernel experiments ("conv_variant").  Process-global. */
+int dvsg_debug_set_option(const char *name, int value);
+
 /* ---------------------------------------------------------------------------------------
  * Measurement hook (bench.py's roofline leg; not part of the reference surface).  While
  * armed for one kernel class, every launch of that class made by this library is bracketed
