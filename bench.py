@@ -141,15 +141,26 @@ def main():
     if dist is not None and not args.no_gather and rank == 0:
         gather_bufs = [[torch.empty((B, H, W, 3), device=dev) for _ in range(world)] for _ in range(2)]
 
-    def step(i, pending):
-        out = outs[i & 1]
+    pending = [None, None]   # in-flight gather per output buffer
+
+    def step(i):
+        slot = i & 1
+        if pending[slot] is not None:
+            # the gather of step i-2 read this buffer: the compute stream must not overwrite it
+            # before that gather is done (the gather of step i-1 keeps overlapping this step)
+            pending[slot].wait()
+            pending[slot] = None
+        out = outs[slot]
         _lib.call("dvsg_stabilize_f32", net.handle, patches.data_ptr(), u_t.data_ptr(), B, H, W, out.data_ptr(),
                   F_t.data_ptr(), 0, 0, ws.data_ptr(), ws_bytes, stream)
         if dist is not None and not args.no_gather:
-            if pending is not None:
-                pending.wait()   # the buffer pair is reused every second step
-            return dist.gather(out, gather_bufs[i & 1] if rank == 0 else None, dst=0, async_op=True)
-        return None
+            pending[slot] = dist.gather(out, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for slot in (0, 1):
+            if pending[slot] is not None:
+                pending[slot].wait()
+                pending[slot] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -157,20 +168,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    pending = None
     for i in range(args.warmup):
-        pending = step(i, pending)
-    if pending is not None:
-        pending.wait()
-        pending = None
+        step(i)
+    drain()
     fence()
     if rank == 0:
         _lib.call("dvsg_prof_begin", args.prof_class)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        pending = step(i, pending)
-    if pending is not None:
-        pending.wait()
+        step(i)
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     prof = None

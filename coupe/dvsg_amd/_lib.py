@@ -71,6 +71,9 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     _lib = lib
+    # diagnostic A/B switch for kernel experiments (see dvsg_debug_set_option in the header)
+    if os.environ.get("DVSG_CONV_VARIANT"):
+        check(lib.dvsg_debug_set_option(b"conv_variant", int(os.environ["DVSG_CONV_VARIANT"])), "dvsg_debug_set_option")
     return lib
 
 
