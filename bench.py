@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the batch of one step is split over (LocNet.stabilize); 2 is ~4 %% faster "
+                         "but concurrent launches make the per-kernel hipEvent durations of `roofline` meaningless")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,7 +125,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm; rendezvous comes from the launcher's MASTER_ADDR / MASTER_PORT
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from coupe.dvsg_amd import _lib
     from coupe.dvsg_amd.networks import LocNet
@@ -135,8 +139,6 @@ def main():
     u_t = patches[..., 18:].contiguous()
     outs = [torch.empty((B, H, W, 3), device=dev) for _ in range(2)]
     F_t = torch.empty((B, 25, 2), device=dev)
-    ws, ws_bytes = net.workspace(B, H, W)
-    stream = torch.cuda.current_stream().cuda_stream
     gather_bufs = None
     if dist is not None and not args.no_gather and rank == 0:
         gather_bufs = [[torch.empty((B, H, W, 3), device=dev) for _ in range(world)] for _ in range(2)]
@@ -151,8 +153,7 @@ def main():
             pending[slot].wait()
             pending[slot] = None
         out = outs[slot]
-        _lib.call("dvsg_stabilize_f32", net.handle, patches.data_ptr(), u_t.data_ptr(), B, H, W, out.data_ptr(),
-                  F_t.data_ptr(), 0, 0, ws.data_ptr(), ws_bytes, stream)
+        net.stabilize(patches, u_t, out, F_t, n_streams=args.streams)   # -> dvsg_stabilize_f32
         if dist is not None and not args.no_gather:
             pending[slot] = dist.gather(out, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
 
@@ -165,7 +166,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -214,7 +215,7 @@ def main():
             "config": {"workload": "configs[1]: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU"
                                    % (B, W, H),
                        "batch_per_gpu": B, "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
-                       "gather": bool(dist is not None and not args.no_gather),
+                       "gather": bool(dist is not None and not args.no_gather), "streams_per_gpu": args.streams,
                        "weights": "synthetic seed 0 (reference ships no checkpoint)"},
             "roofline": roofline,
         }
@@ -222,7 +223,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights, H, W)
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

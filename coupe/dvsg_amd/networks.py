@@ -57,14 +57,49 @@ class LocNet(object):
         except Exception:
             pass
 
-    def workspace(self, B, H, W):
+    def workspace(self, B, H, W, slot=0):
         need = ctypes.c_size_t()
         _lib.call("dvsg_locnet_workspace_bytes", self.handle, B, H, W, ctypes.byref(need))
-        if self._ws is None or self._ws.numel() < need.value:
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need.value:
             import torch
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=device())
-        return self._ws, need.value
+            self._ws[slot] = None
+            ws = self._ws[slot] = torch.empty(need.value, dtype=torch.uint8, device=device())
+        return ws, need.value
+
+    def stabilize(self, patches, u_t, out, F, xs=None, ys=None, n_streams=1):
+        """`dvsg_stabilize_f32` on device tensors, optionally with the batch split over
+        `n_streams` side streams: every conv launch covers the chip in a few rounds of tiles and
+        its last round is only partly full; launches from two independent half batches fill each
+        other's tails (+4 % at B=16 720p).  Results do not depend on the split (samples are
+        independent); the caller's stream sees one fork / join."""
+        import torch
+        B, H, W, _ = u_t.shape
+        if n_streams <= 1 or B < 2 * n_streams:
+            ws, nbytes = self.workspace(B, H, W)
+            _lib.call("dvsg_stabilize_f32", self.handle, ptr(patches), ptr(u_t), B, H, W, ptr(out), ptr(F),
+                      ptr(xs), ptr(ys), ptr(ws), nbytes, stream())
+            return
+        if getattr(self, "_side", None) is None or len(self._side) != n_streams:
+            self._side = [torch.cuda.Stream() for _ in range(n_streams)]
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        per = -(-B // n_streams)
+        for i, side in enumerate(self._side):
+            b0, b1 = i * per, min(B, (i + 1) * per)
+            if b0 >= b1:
+                break
+            side.wait_event(fork)
+            ws, nbytes = self.workspace(b1 - b0, H, W, slot=1 + i)
+            _lib.call("dvsg_stabilize_f32", self.handle, ptr(patches[b0:b1]), ptr(u_t[b0:b1]), b1 - b0, H, W,
+                      ptr(out[b0:b1]), ptr(F[b0:b1]), ptr(xs[b0 * H * W:b1 * H * W]) if xs is not None else 0,
+                      ptr(ys[b0 * H * W:b1 * H * W]) if ys is not None else 0, ptr(ws), nbytes, side.cuda_stream)
+            join = torch.cuda.Event()
+            join.record(side)
+            cur.wait_event(join)
 
     def forward(self, patches, param_dim=25):
         t = as_dev(patches)
