@@ -50,6 +50,24 @@ def gpu_windows(B, H, W, seed, dev, S=7):
     return x
 
 
+def pmc_traffic(cls, B, H, W):
+    """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes
+    (profiles/rNN_traffic.json, written by tools/summarize_profiles.py from separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command with the gfx950 corrections of MI355X_MICROARCH.md).
+    Counters cannot be read from inside the timed run, so this is the last profiled value; it is
+    only reported when the workload shape is the profiled one (B=16, 720p)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files or (B, H, W) != (16, 720, 1280):
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)["classes"].get(str(cls))
+        return (c["bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if c else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def usable_cores():
     """Host cores this process may actually use: min(affinity, cgroup quota), and never more
     than the 16-core share a one-GPU box grants (oversubscribing torch-CPU is slower)."""
@@ -204,9 +222,12 @@ def main():
             achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS}
-        roofline.update({"traffic": None, "kernel": KERNEL_CLASSES[cls], "launches": launches,
+        traffic, traffic_src = pmc_traffic(cls, B, H, W)
+        roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "kernel": KERNEL_CLASSES[cls], "launches": launches,
                          "avg_launch_ms": total_ms / max(launches, 1),
-                         "algorithmic_per_launch": (flops if cls <= 2 else nbytes) / max(launches, 1)})
+                         "algorithmic_per_launch": (flops if cls <= 2 else nbytes) / max(launches, 1),
+                         "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
         line = {
             "metric": "stabilized frames/sec (1280x720 RGB)", "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -19,7 +19,8 @@ struct ConvGemm {
   int relu;
 };
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
-void set_conv_variant(int v);  // diagnostic A/B switch (dvsg_debug_set_option)
+void set_conv_variant(int v);   // diagnostic A/B switches (dvsg_debug_set_option)
+void set_conv1_variant(int v);
 
 // conv1: 7x7 stride 2, explicit pad 3, C_in = 21 -> 64, with scale_RGB fused into the LDS
 // load stage (networks.py:6-16 + slim conv2d_same root).  wt1 is [7][64][kConv1Ld]:

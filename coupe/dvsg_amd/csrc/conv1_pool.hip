@@ -23,19 +23,24 @@ namespace {
 // happens AFTER scale_RGB, so pad taps must be 0 in the scaled domain: the scale is applied
 // per element while staging (valid elements only), and the group reversal is a permutation
 // of conv1's input channels that is folded into the weights at load time (locnet.hip).
+//
+// NW waves per workgroup: NW/2 along the pixels x 2 along the channels.
 // ----------------------------------------------------------------------------------------
 constexpr int C1_TILE = 128;
 constexpr int C1_SEG = (2 * (C1_TILE - 1) + 7) * kConv1Cin;  // 5481
 constexpr int C1_SEG_PAD = 5488;
-constexpr int C1_INLOADS = (C1_SEG_PAD + 255) / 256;         // 22
 constexpr int C1_WELEMS = 64 * kConv1Ld;                      // 9600 floats per kernel row
-constexpr int C1_WLOADS = (C1_WELEMS / 4 + 255) / 256;        // 10 float4
+constexpr int C1_LDC = 68;                                    // epilogue tile row stride
 
-__global__ __launch_bounds__(256, 2) void conv1_kernel(const float *__restrict__ x,
-                                                      const float *__restrict__ wt1,
-                                                      const float *__restrict__ bias,
-                                                      float *__restrict__ y, int H, int W, int Ho,
-                                                      int Wo, int wtiles) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
+void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, const float *__restrict__ bias,
+                  float *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
+  constexpr int NT = 64 * NW;
+  constexpr int MI = 4 / (NW / 2);                       // 32-pixel MFMA blocks per wave: 2 or 1
+  constexpr int INLOADS = (C1_SEG_PAD + NT - 1) / NT;    // 22 or 11 dwords per thread per kernel row
+  constexpr int WLOADS = (C1_WELEMS / 4 + NT - 1) / NT;  // 10 or 5 float4
+  static_assert(C1_TILE * C1_LDC <= C1_WELEMS, "epilogue tile must fit in the weight stage");
   __shared__ __attribute__((aligned(16))) float w_s[C1_WELEMS];
   __shared__ __attribute__((aligned(16))) float in_s[C1_SEG_PAD];
   const int tid = threadIdx.x;
@@ -52,16 +57,16 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const float *__restrict__
 
   // element e of the staged segment is input-row float (2 wo0 - 3) * 21 + e.  Loads are issued
   // UNCONDITIONALLY from a clamped index (a predicated load whose value feeds arithmetic makes
-  // hipcc wait for each load in turn: 22 serialised L2 round trips per kernel row); validity
-  // is a per-thread bit mask applied when the value is written to LDS.
+  // hipcc wait for each load in turn: serialised L2 round trips); validity is a per-thread
+  // bit mask applied when the value is written to LDS.
   const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[C1_INLOADS];
-  int idx_i[C1_INLOADS];
+  float mean_i[INLOADS];
+  int idx_i[INLOADS];
   unsigned col_ok = 0;
 #pragma unroll
-  for (int i = 0; i < C1_INLOADS; ++i) {
-    const int e = tid + 256 * i;
+  for (int i = 0; i < INLOADS; ++i) {
+    const int e = tid + NT * i;
     const long ge = seg0 + e;
     // raw channel c of group g = c / 7 lands in output group 2 - g and gets that group's mean
     const int c = e % kConv1Cin;
@@ -72,8 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const float *__restrict__
     idx_i[i] = ok ? (int)ge : 0;
   }
 
-  float in_reg[C1_INLOADS];
-  floatx4 w_reg[C1_WLOADS];
+  float in_reg[INLOADS];
+  floatx4 w_reg[WLOADS];
   bool row_ok = false;  // validity of the input row whose values sit in in_reg
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
     const int hi = 2 * ho + kh - 3;
@@ -81,34 +86,34 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const float *__restrict__
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = x + ((long)b * H + hc) * row_elems;
 #pragma unroll
-    for (int i = 0; i < C1_INLOADS; ++i) in_reg[i] = xrow[idx_i[i]];
+    for (int i = 0; i < INLOADS; ++i) in_reg[i] = xrow[idx_i[i]];
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1 + (size_t)kh * C1_WELEMS);
 #pragma unroll
-    for (int i = 0; i < C1_WLOADS; ++i) {
-      const int q = tid + 256 * i;
+    for (int i = 0; i < WLOADS; ++i) {
+      const int q = tid + NT * i;
       w_reg[i] = wsrc[q < C1_WELEMS / 4 ? q : 0];
     }
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
     const unsigned ok = row_ok ? col_ok : 0u;
 #pragma unroll
-    for (int i = 0; i < C1_INLOADS; ++i) {
-      const int e = tid + 256 * i;
+    for (int i = 0; i < INLOADS; ++i) {
+      const int e = tid + NT * i;
       // zero padding lives in the SCALED domain; x*255 and the subtraction round separately,
-      // as the two TF ops do
-      const float v = __fsub_rn(__fmul_rn(in_reg[i], 255.0f), mean_i[i]);
+      // as the two TF ops do (this file is compiled with -ffp-contract=off)
+      const float v = in_reg[i] * 255.0f - mean_i[i];
       if (e < C1_SEG_PAD) in_s[e] = ((ok >> i) & 1u) ? v : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < C1_WLOADS; ++i) {
-      const int q = tid + 256 * i;
+    for (int i = 0; i < WLOADS; ++i) {
+      const int q = tid + NT * i;
       if (q < C1_WELEMS / 4) reinterpret_cast<floatx4 *>(w_s)[q] = w_reg[i];
     }
   };
 
-  floatx16 acc[2];
+  floatx16 acc[MI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[mi][q] = 0.f;
 
@@ -119,30 +124,43 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const float *__restrict__
     __syncthreads();
     if (kh + 1 < 7) load_stage(kh + 1);
     __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
-    const float *a0 = in_s + 2 * kConv1Cin * (wm * 64 + r) + 2 * h;
-    const float *a1 = a0 + 2 * kConv1Cin * 32;
+    const float *a0 = in_s + 2 * kConv1Cin * (wm * 32 * MI + r) + 2 * h;
     const float *bp = w_s + (wn * 32 + r) * kConv1Ld + 2 * h;
 #pragma unroll 4
     for (int u = 0; u < kConv1Kpad / 4; ++u) {
-      const float2 va0 = *reinterpret_cast<const float2 *>(a0 + 4 * u);
-      const float2 va1 = *reinterpret_cast<const float2 *>(a1 + 4 * u);
+      float2 va[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        va[mi] = *reinterpret_cast<const float2 *>(a0 + mi * (2 * kConv1Cin * 32) + 4 * u);
       const float2 vb = *reinterpret_cast<const float2 *>(bp + 4 * u);
-      acc[0] = mfma32(va0.x, vb.x, acc[0]);
-      acc[1] = mfma32(va1.x, vb.x, acc[1]);
-      acc[0] = mfma32(va0.y, vb.y, acc[0]);
-      acc[1] = mfma32(va1.y, vb.y, acc[1]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32(va[mi].x, vb.x, acc[mi]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32(va[mi].y, vb.y, acc[mi]);
     }
   }
 
-  const int n = wn * 32 + r;
-  const float bs = bias[n];
+  // ---- epilogue: transpose through the (idle) weight stage so stores are float4s along channels
+  float *Cs = w_s;
+  __syncthreads();
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int wo = wo0 + wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (wo < Wo) y[(((size_t)b * Ho + ho) * Wo + wo) * 64 + n] = fmaxf(acc[mi][q] + bs, 0.f);
-    }
+    for (int q = 0; q < 16; ++q)
+      Cs[(wm * 32 * MI + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + wn * 32 + r] = acc[mi][q];
+  __syncthreads();
+  const int col4 = tid & 15, row0 = tid >> 4;
+  const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
+  float *yrow = y + (((size_t)b * Ho + ho) * Wo + wo0) * 64 + 4 * col4;
+#pragma unroll 4
+  for (int row = row0; row < C1_TILE; row += NT / 16) {
+    if (wo0 + row >= Wo) break;
+    float4 v = *reinterpret_cast<const float4 *>(Cs + row * C1_LDC + 4 * col4);
+    v.x = fmaxf(v.x + b4.x, 0.f);
+    v.y = fmaxf(v.y + b4.y, 0.f);
+    v.z = fmaxf(v.z + b4.z, 0.f);
+    v.w = fmaxf(v.w + b4.w, 0.f);
+    *reinterpret_cast<float4 *>(yrow + (size_t)row * 64) = v;
   }
 }
 
@@ -180,7 +198,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
   }
 }
 
+int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 waves (measured equal or better), 1 = 8
+
 }  // namespace
+
+void set_conv1_variant(int v) { g_conv1_variant = v; }
 
 int launch_conv1(const float *x, const float *wt1, const float *bias, float *y, int B, int H, int W,
                  int Ho, int Wo, hipStream_t s) {
@@ -190,8 +212,12 @@ int launch_conv1(const float *x, const float *wt1, const float *bias, float *y, 
   DVSG_REQUIRE((long)W * kConv1Cin < (1L << 31), "conv1: input row too long");
   ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
                  4.0 * ((double)B * H * W * kConv1Cin + (double)B * Ho * Wo * 64));
-  hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, wt1, bias, y, H, W, Ho, Wo,
-                     wtiles);
+  if (g_conv1_variant == 0)
+    hipLaunchKernelGGL(conv1_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, x, wt1, bias, y, H, W, Ho, Wo,
+                       wtiles);
+  else
+    hipLaunchKernelGGL(conv1_kernel<8>, dim3((unsigned)blocks), dim3(512), 0, s, x, wt1, bias, y, H, W, Ho, Wo,
+                       wtiles);
   return check_launch("conv1_kernel");
 }
 

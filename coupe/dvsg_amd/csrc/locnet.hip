@@ -426,6 +426,10 @@ int dvsg_debug_set_option(const char *name, int value) {
     set_conv_variant(value);
     return DVSG_OK;
   }
+  if (std::strcmp(name, "conv1_variant") == 0) {
+    set_conv1_variant(value);
+    return DVSG_OK;
+  }
   return fail(DVSG_ERR_INVALID_ARG, "dvsg_debug_set_option: unknown option %s", name);
 }
 

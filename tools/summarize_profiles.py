@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of tools/profile_round.sh into the committed summaries:
+    python tools/summarize_profiles.py gpurun_out/prof_r01 profiles r01
+writes profiles/<tag>_kernel_stats.csv (rocprofv3 --stats, verbatim), <tag>_pmc_{sq,fetch,write}.csv
+(per kernel symbol sums over the run) and <tag>_traffic.json (HBM-side bytes per launch per kernel
+class, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950
+FETCH_SIZE reads exactly half of a wide coalesced stream, so it is doubled)."""
+import csv
+import glob
+import json
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+CLASSES = {"conv1_kernel": 0, "conv_gemm": None, "maxpool_kernel": 3, "tps_solve_kernel": 5, "tps_warp_kernel": 6,
+           "stn_kernel": 7, "dense_kernel": 4, "avgpool_partial_kernel": 4, "dense_finalize_kernel": 4}
+
+
+def short(n):
+    n = re.sub(r"dvsg::\(anonymous namespace\)::", "", n)
+    return re.sub(r"\(.*", "", n).replace("void ", "")
+
+
+def kclass(name):
+    s = short(name)
+    if s.startswith("conv_gemm"):
+        m = re.match(r"conv_gemm(?:_glds)?_kernel<(\d+), (\d+), (\d+), (\d+)", s)
+        return 1 if m and m.group(4) == "3" else 2
+    for k, v in CLASSES.items():
+        if s.startswith(k):
+            return v
+    return None
+
+
+def counters(d):
+    cc = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    kt = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
+    dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt))}
+    per = defaultdict(lambda: defaultdict(float))
+    disp = defaultdict(set)
+    for r in csv.DictReader(open(cc)):
+        k = r["Kernel_Name"]
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return per, disp, dur
+
+
+def write_pmc(d, path):
+    per, disp, dur = counters(d)
+    names = sorted({c for k in per for c in per[k]})
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "total_us"] + names)
+        for k in sorted(per, key=lambda k: -sum(dur.get(i, 0) for i in disp[k])):
+            if kclass(k) is None:
+                continue
+            w.writerow([short(k), len(disp[k]), "%.1f" % sum(dur.get(i, 0) for i in disp[k])] + ["%.6g" % per[k][n] for n in names])
+    return per, disp
+
+
+def main(src, dst, tag):
+    stats = glob.glob(src + "/stats/**/*_kernel_stats.csv", recursive=True)[0]
+    shutil.copy(stats, "%s/%s_kernel_stats.csv" % (dst, tag))
+    write_pmc(src + "/pmc_sq", "%s/%s_pmc_sq.csv" % (dst, tag))
+    fetch, fdisp = write_pmc(src + "/pmc_fetch", "%s/%s_pmc_fetch.csv" % (dst, tag))
+    write, wdisp = write_pmc(src + "/pmc_write", "%s/%s_pmc_write.csv" % (dst, tag))
+    traffic = {}
+    for cls in range(8):
+        fb = sum(fetch[k]["FETCH_SIZE"] for k in fetch if kclass(k) == cls) * 1024.0 * 2.0
+        fn = sum(len(fdisp[k]) for k in fetch if kclass(k) == cls)
+        wb = sum(write[k]["WRITE_SIZE"] for k in write if kclass(k) == cls) * 1024.0
+        wn = sum(len(wdisp[k]) for k in write if kclass(k) == cls)
+        if fn and wn:
+            traffic[str(cls)] = {"fetch_bytes_per_launch": fb / fn, "write_bytes_per_launch": wb / wn,
+                                 "bytes_per_launch": fb / fn + wb / wn, "launches_profiled": fn}
+    json.dump({"note": "FETCH_SIZE x1024 x2 (gfx950 half-count correction) + WRITE_SIZE x1024, separate --pmc passes; "
+                       "memory-side (fabric) requests, Infinity-Cache hits included", "classes": traffic},
+              open("%s/%s_traffic.json" % (dst, tag), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
