@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*>", 2: "conv_gemm_kernel<*,1,*>",
                   3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel"}
@@ -50,7 +51,7 @@ def gpu_windows(B, H, W, seed, dev, S=7):
     return x
 
 
-def pmc_traffic(cls, B, H, W):
+def pmc_traffic(cls, B, H, W, precision="f32"):
     """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes
     (profiles/rNN_traffic.json, written by tools/summarize_profiles.py from separate FETCH_SIZE /
     WRITE_SIZE runs of this same command with the gfx950 corrections of MI355X_MICROARCH.md).
@@ -58,7 +59,7 @@ def pmc_traffic(cls, B, H, W):
     only reported when the workload shape is the profiled one (B=16, 720p)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files or (B, H, W) != (16, 720, 1280):
+    if not files or (B, H, W) != (16, 720, 1280) or precision != "f32":
         return None, None
     try:
         with open(files[-1]) as f:
@@ -126,6 +127,8 @@ def main():
     ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
+                    help="f32 (default, the reference's arithmetic: the headline number) or f16 activations/weights")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the batch of one step is split over (LocNet.stabilize); 2 is ~4 %% faster "
                          "but concurrent launches make the per-kernel hipEvent durations of `roofline` meaningless")
@@ -171,7 +174,7 @@ def main():
             pending[slot].wait()
             pending[slot] = None
         out = outs[slot]
-        net.stabilize(patches, u_t, out, F_t, n_streams=args.streams)   # -> dvsg_stabilize_f32
+        net.stabilize(patches, u_t, out, F_t, n_streams=args.streams, precision=args.precision)  # dvsg_stabilize_*
         if dist is not None and not args.no_gather:
             pending[slot] = dist.gather(out, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
 
@@ -216,13 +219,13 @@ def main():
         cls = args.prof_class
         if cls <= 2:
             achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
-            roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_F32_MFMA_TFLOPS}
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" or cls == 0 else PEAK_F16_MFMA_TFLOPS
+            roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
         else:
             achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS}
-        traffic, traffic_src = pmc_traffic(cls, B, H, W)
+        traffic, traffic_src = pmc_traffic(cls, B, H, W, args.precision)
         roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel": KERNEL_CLASSES[cls], "launches": launches,
                          "avg_launch_ms": total_ms / max(launches, 1),
@@ -231,7 +234,7 @@ def main():
         line = {
             "metric": "stabilized frames/sec (1280x720 RGB)", "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": "configs[1]: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU"
                                    % (B, W, H),

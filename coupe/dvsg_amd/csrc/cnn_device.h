@@ -1,14 +1,14 @@
 // Device helpers shared by the localizationNet kernels.
 //
-// Precision: float32 storage, exact-f32 matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered
-// fmaf chain, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+// Precision kF32: float32 storage, exact-f32 matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered
+// fmaf chain, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).  Precision kF16: float16 storage,
+// v_mfma_f32_32x32x16_f16 with float32 accumulation (~2.5 PFLOP/s dense peak).
 //
-// Fragment scheme: the 32x32x2 MFMA takes ONE f32 per lane per operand -- lane (r = l & 31,
-// h = l >> 5) supplies A[r][k_h] and B[k_h][r].  The order in which the k values of a tile are
-// fed is free as long as A and B agree, so each lane reads a short run of CONSECUTIVE k (a
-// float4 / float2 from a K-contiguous LDS row) and feeds it over consecutive MFMAs; lane half h
-// takes the second half of the run.  That turns the operand fetch into conflict-free
-// ds_read_b128 / ds_read_b64 with no transposes anywhere.
+// Fragment scheme: lane (r = l & 31, h = l >> 5) of a 32x32 MFMA supplies row r of A and column
+// r of B for the k values owned by lane half h.  The order in which the k values of a tile are
+// fed is free as long as A and B agree, so each lane reads ONE 16-byte run of consecutive k from
+// a K-contiguous LDS row: four f32 fed over four 32x32x2 MFMAs, or eight f16 that are exactly
+// one 32x32x16 operand.  Operand fetch is a conflict-free ds_read_b128 with no transposes.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,9 +16,52 @@ namespace dvsg {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// One 16-byte fragment chunk (k-run) of A and of B -> accumulate into c.
+template <typename T>
+struct Frag;
+
+template <>
+struct Frag<float> {
+  typedef floatx4 type;
+  static constexpr int kElems = 4;  // k values per 16-byte chunk
+  static __device__ __forceinline__ floatx16 mma(floatx4 a, floatx4 b, floatx16 c) {
+    c = mfma32(a[0], b[0], c);
+    c = mfma32(a[1], b[1], c);
+    c = mfma32(a[2], b[2], c);
+    return mfma32(a[3], b[3], c);
+  }
+};
+
+template <>
+struct Frag<_Float16> {
+  typedef halfx8 type;
+  static constexpr int kElems = 8;
+  static __device__ __forceinline__ floatx16 mma(halfx8 a, halfx8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// Four consecutive channels of an activation tensor <-> float4.
+__device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load4(const _Float16 *p) {
+  const halfx4 v = *reinterpret_cast<const halfx4 *>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void store4(_Float16 *p, float4 v) {
+  halfx4 o;
+  o[0] = (_Float16)v.x;
+  o[1] = (_Float16)v.y;
+  o[2] = (_Float16)v.z;
+  o[3] = (_Float16)v.w;
+  *reinterpret_cast<halfx4 *>(p) = o;
 }
 
 // XCD-aware block remap (bijective for any grid size): the hardware deals consecutive

@@ -1,18 +1,29 @@
-// Launch interface of the localizationNet kernels (cnn_kernels.hip), used by locnet.hip.
+// Launch interface of the localizationNet kernels (conv_gemm.hip, conv1_pool.hip, head.hip),
+// used by locnet.hip.
+//
+// Two storage precisions share every kernel through a template parameter:
+//   kF32  float32 activations / weights, exact-f32 matrix cores (v_mfma_f32_32x32x2_f32)
+//   kF16  float16 activations / weights, v_mfma_f32_32x32x16_f16 with float32 accumulation;
+//         conv1 still multiplies in f32 (its input is the reference's float32 frames) and
+//         writes f16; bias, accumulators and the dense head stay float32.
 #pragma once
 #include "common.h"
 
 namespace dvsg {
 
-// Implicit-GEMM convolution (1x1 or 3x3, NHWC float32, C_in % 32 == 0, C_out % 64 == 0):
+enum Precision { kF32 = 0, kF16 = 1 };
+inline size_t elem_size(int prec) { return prec == kF16 ? 2 : 4; }
+
+// Implicit-GEMM convolution (1x1 or 3x3, NHWC, C_in % 64 == 0 (f16) / 32 (f32), C_out % 64 == 0):
 //   y[m, n] = act( sum_k A[m, k] * wt[n, k] + bias[n] (+ res[...]) )
 // with m = (b, ho, wo), k = (kh, kw, c).  wt is [C_out][K] (K contiguous, BN scale folded in).
 struct ConvGemm {
-  const float *x;     // [B,H,W,Cin]
-  const float *wt;    // [Cout][ksize*ksize*Cin]
+  int prec;           // kF32 / kF16: element type of x, wt, res, y
+  const void *x;      // [B,H,W,Cin]
+  const void *wt;     // [Cout][ksize*ksize*Cin]
   const float *bias;  // [Cout]
-  const float *res;   // optional residual [B,res_H,res_W,Cout], sampled at (ho*res_stride, wo*res_stride)
-  float *y;           // [B,Ho,Wo,Cout]
+  const void *res;    // optional residual [B,res_H,res_W,Cout], sampled at (ho*res_stride, wo*res_stride)
+  void *y;            // [B,Ho,Wo,Cout]
   int B, H, W, Cin, Ho, Wo, Cout;
   int ksize, stride, pad;
   int res_H, res_W, res_stride;
@@ -23,25 +34,28 @@ void set_conv_variant(int v);   // diagnostic A/B switches (dvsg_debug_set_optio
 void set_conv1_variant(int v);
 
 // conv1: 7x7 stride 2, explicit pad 3, C_in = 21 -> 64, with scale_RGB fused into the LDS
-// load stage (networks.py:6-16 + slim conv2d_same root).  wt1 is [7][64][kConv1Ld]:
+// load stage (networks.py:6-16 + slim conv2d_same root).  wt1 is [7][64][kConv1Ld] float32:
 // per kernel row kh, per output channel, the 7*21 (kw, c) taps in memory order of the
 // input row (+ zero padding), BN scale folded, channel-group reversal folded.
 constexpr int kConv1Cin = 21;
 constexpr int kConv1K = 7 * kConv1Cin;   // 147 taps per kernel row
 constexpr int kConv1Kpad = 148;          // rounded to the 4-k MFMA step
 constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conflict-free ds_read_b64)
-int launch_conv1(const float *x, const float *wt1, const float *bias, float *y, int B, int H, int W,
-                 int Ho, int Wo, hipStream_t s);
+int launch_conv1(int out_prec, const float *x, const float *wt1, const float *bias, void *y, int B, int H,
+                 int W, int Ho, int Wo, hipStream_t s);
 
-// 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 4 == 0.
-int launch_maxpool(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
+// 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 8 == 0.
+int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
                    int pad_left, hipStream_t s);
 
-// Global average pool as partial sums: part[b][s][c] = sum over the s-th slice of HW.
+// Global average pool as float32 partial sums: part[b][s][c] = sum over the s-th slice of HW.
 constexpr int kPoolSplits = 8;
-int launch_avgpool_partial(const float *x, float *part, int B, int HW, int C, hipStream_t s);
+int launch_avgpool_partial(int prec, const void *x, float *part, int B, int HW, int C, hipStream_t s);
 
-// Dense layer on split partial sums (see cnn_kernels.hip).
+// Element-wise float16 -> float32 (parity taps of a float16 run).
+int launch_f16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
+
+// Dense layer on split partial sums (see head.hip); float32 throughout.
 constexpr int kDenseSplits = 8;
 int launch_dense(const float *xin, int s_in, const float *bias_in, float scale_in, int lrelu_in,
                  const float *W, float *out_part, int B, int K, int N, hipStream_t s);

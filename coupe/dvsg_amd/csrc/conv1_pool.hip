@@ -32,10 +32,10 @@ constexpr int C1_SEG_PAD = 5488;
 constexpr int C1_WELEMS = 64 * kConv1Ld;                      // 9600 floats per kernel row
 constexpr int C1_LDC = 68;                                    // epilogue tile row stride
 
-template <int NW>
+template <int NW, typename TO>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
 void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, const float *__restrict__ bias,
-                  float *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
+                  TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
   constexpr int NT = 64 * NW;
   constexpr int MI = 4 / (NW / 2);                       // 32-pixel MFMA blocks per wave: 2 or 1
   constexpr int INLOADS = (C1_SEG_PAD + NT - 1) / NT;    // 22 or 11 dwords per thread per kernel row
@@ -151,7 +151,7 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
   __syncthreads();
   const int col4 = tid & 15, row0 = tid >> 4;
   const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
-  float *yrow = y + (((size_t)b * Ho + ho) * Wo + wo0) * 64 + 4 * col4;
+  TO *yrow = y + (((size_t)b * Ho + ho) * Wo + wo0) * 64 + 4 * col4;
 #pragma unroll 4
   for (int row = row0; row < C1_TILE; row += NT / 16) {
     if (wo0 + row >= Wo) break;
@@ -160,7 +160,7 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     v.y = fmaxf(v.y + b4.y, 0.f);
     v.z = fmaxf(v.z + b4.z, 0.f);
     v.w = fmaxf(v.w + b4.w, 0.f);
-    *reinterpret_cast<float4 *>(yrow + (size_t)row * 64) = v;
+    store4(yrow + (size_t)row * 64, v);
   }
 }
 
@@ -168,9 +168,10 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
 // 3x3 / stride 2 max pool with TF 'SAME' padding (pad_before = pad_total / 2: nothing on
 // the top/left for even sizes).  One thread = one output pixel x 4 channels.
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                     int H, int W, int C4, int Ho, int Wo, int pad_top,
-                                                     int pad_left, size_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, T *__restrict__ y, int H, int W,
+                                                     int C4, int Ho, int Wo, int pad_top, int pad_left,
+                                                     size_t total) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int c4 = (int)(e % C4);
     size_t t = e / C4;
@@ -187,14 +188,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ 
       for (int j = 0; j < 3; ++j) {
         const int wi = 2 * wo - pad_left + j;
         if (wi < 0 || wi >= W) continue;
-        const float4 v = reinterpret_cast<const float4 *>(x)[((b * H + hi) * W + wi) * C4 + c4];
+        const float4 v = load4(x + (((b * H + hi) * W + wi) * C4 + c4) * 4);
         m.x = fmaxf(m.x, v.x);
         m.y = fmaxf(m.y, v.y);
         m.z = fmaxf(m.z, v.z);
         m.w = fmaxf(m.w, v.w);
       }
     }
-    reinterpret_cast<float4 *>(y)[e] = m;
+    store4(y + e * 4, m);
   }
 }
 
@@ -204,32 +205,41 @@ int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 wa
 
 void set_conv1_variant(int v) { g_conv1_variant = v; }
 
-int launch_conv1(const float *x, const float *wt1, const float *bias, float *y, int B, int H, int W,
-                 int Ho, int Wo, hipStream_t s) {
+int launch_conv1(int out_prec, const float *x, const float *wt1, const float *bias, void *y, int B, int H,
+                 int W, int Ho, int Wo, hipStream_t s) {
   const int wtiles = ceil_div(Wo, C1_TILE);
   const long blocks = (long)wtiles * Ho * B;
   DVSG_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv1: grid of %ld workgroups out of range", blocks);
   DVSG_REQUIRE((long)W * kConv1Cin < (1L << 31), "conv1: input row too long");
   ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
-                 4.0 * ((double)B * H * W * kConv1Cin + (double)B * Ho * Wo * 64));
-  if (g_conv1_variant == 0)
-    hipLaunchKernelGGL(conv1_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, x, wt1, bias, y, H, W, Ho, Wo,
-                       wtiles);
-  else
-    hipLaunchKernelGGL(conv1_kernel<8>, dim3((unsigned)blocks), dim3(512), 0, s, x, wt1, bias, y, H, W, Ho, Wo,
-                       wtiles);
+                 4.0 * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
+  const dim3 grid((unsigned)blocks);
+  if (out_prec == kF16) {
+    hipLaunchKernelGGL((conv1_kernel<4, _Float16>), grid, dim3(256), 0, s, x, wt1, bias,
+                       static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
+  } else if (g_conv1_variant == 0) {
+    hipLaunchKernelGGL((conv1_kernel<4, float>), grid, dim3(256), 0, s, x, wt1, bias, static_cast<float *>(y), H,
+                       W, Ho, Wo, wtiles);
+  } else {
+    hipLaunchKernelGGL((conv1_kernel<8, float>), grid, dim3(512), 0, s, x, wt1, bias, static_cast<float *>(y), H,
+                       W, Ho, Wo, wtiles);
+  }
   return check_launch("conv1_kernel");
 }
 
-int launch_maxpool(const float *x, float *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
+int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
                    int pad_left, hipStream_t s) {
   DVSG_REQUIRE(C % 4 == 0, "maxpool: C=%d must be a multiple of 4", C);
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
   const size_t want = (total + 255) / 256;
   const int blocks = (int)(want < 16384 ? want : 16384);
-  ProfScope prof(kClsMaxpool, s, 0.0, 4.0 * C * ((double)B * H * W + (double)B * Ho * Wo));
-  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, C / 4, Ho, Wo, pad_top,
-                     pad_left, total);
+  ProfScope prof(kClsMaxpool, s, 0.0, (double)elem_size(prec) * C * ((double)B * H * W + (double)B * Ho * Wo));
+  if (prec == kF16)
+    hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16 *>(x),
+                       static_cast<_Float16 *>(y), H, W, C / 4, Ho, Wo, pad_top, pad_left, total);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<const float *>(x),
+                       static_cast<float *>(y), H, W, C / 4, Ho, Wo, pad_top, pad_left, total);
   return check_launch("maxpool_kernel");
 }
 

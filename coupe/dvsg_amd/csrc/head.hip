@@ -3,12 +3,14 @@
 // (networks.py:31,36-44).  Tiny (6.8 MMAC per frame) and latency-bound: every stage writes
 // deterministic split partial sums and the next stage folds "sum the partials, add bias,
 // leaky-ReLU" into its operand load -- no atomics, bitwise reproducible.
+#include "cnn_device.h"
 #include "cnn_kernels.h"
 
 namespace dvsg {
 namespace {
 
-__global__ __launch_bounds__(256) void avgpool_partial_kernel(const float *__restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_partial_kernel(const T *__restrict__ x,
                                                              float *__restrict__ part, int B, int HW,
                                                              int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -16,9 +18,9 @@ __global__ __launch_bounds__(256) void avgpool_partial_kernel(const float *__res
   if (c >= C) return;
   const int per = (HW + kPoolSplits - 1) / kPoolSplits;
   const int i0 = s * per, i1 = min(HW, i0 + per);
-  const float *px = x + ((size_t)b * HW) * C + c;
+  const T *px = x + ((size_t)b * HW) * C + c;
   float acc = 0.f;
-  for (int i = i0; i < i1; ++i) acc += px[(size_t)i * C];
+  for (int i = i0; i < i1; ++i) acc += (float)px[(size_t)i * C];
   part[((size_t)b * kPoolSplits + s) * C + c] = acc;
 }
 
@@ -89,12 +91,29 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(const float *__rest
   out[e] = bias ? v + bias[n] : v;
 }
 
+__global__ __launch_bounds__(256) void f16_to_f32_kernel(const _Float16 *__restrict__ x, float *__restrict__ y,
+                                                        size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) y[e] = (float)x[e];
+}
+
 }  // namespace
 
-int launch_avgpool_partial(const float *x, float *part, int B, int HW, int C, hipStream_t s) {
-  ProfScope prof(kClsHead, s, 0.0, 4.0 * (double)B * HW * C);
-  hipLaunchKernelGGL(avgpool_partial_kernel, dim3(ceil_div(C, 256), B, kPoolSplits), dim3(256), 0, s, x,
-                     part, B, HW, C);
+int launch_f16_to_f32(const void *x, float *y, size_t n, hipStream_t s) {
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s,
+                     static_cast<const _Float16 *>(x), y, n);
+  return check_launch("f16_to_f32_kernel");
+}
+
+int launch_avgpool_partial(int prec, const void *x, float *part, int B, int HW, int C, hipStream_t s) {
+  ProfScope prof(kClsHead, s, 0.0, (double)elem_size(prec) * B * HW * C);
+  const dim3 grid(ceil_div(C, 256), B, kPoolSplits);
+  if (prec == kF16)
+    hipLaunchKernelGGL(avgpool_partial_kernel<_Float16>, grid, dim3(256), 0, s, static_cast<const _Float16 *>(x),
+                       part, B, HW, C);
+  else
+    hipLaunchKernelGGL(avgpool_partial_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(x), part,
+                       B, HW, C);
   return check_launch("avgpool_partial_kernel");
 }
 

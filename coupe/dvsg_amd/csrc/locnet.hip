@@ -1,6 +1,7 @@
 // Host side of localizationNet (networks.py:30-46) and of the fused evaluation graph
 // (model.py:98-123): checkpoint ingestion (BatchNorm folding, weight re-layout for the MFMA
-// fragment scheme of cnn_kernels.hip), workspace planning and the launch sequence.
+// fragment scheme of conv_gemm.hip / conv1_pool.hip, float16 copies), workspace planning and the
+// launch sequence for both storage precisions.
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -29,8 +30,10 @@ struct HostArray {
 struct ConvLayer {
   int ksize, cin, cout, stride;
   bool relu;
-  float *wt = nullptr;    // device, [cout][k*k*cin] (conv1: [7][64][kConv1Ld])
-  float *bias = nullptr;  // device, [cout]
+  float *wt = nullptr;        // device, [cout][k*k*cin] float32 (conv1: [7][64][kConv1Ld])
+  _Float16 *wt16 = nullptr;   // device, same layout in float16 (not for conv1)
+  float *bias = nullptr;      // device, [cout] float32
+  const void *weights(int prec) const { return prec == kF16 ? (const void *)wt16 : (const void *)wt; }
 };
 
 struct Unit {
@@ -87,12 +90,13 @@ int find(const ArrayMap &m, const std::string &name, std::initializer_list<int64
   return DVSG_OK;
 }
 
-int upload(dvsg_locnet *net, const std::vector<float> &h, float **dev) {
+template <typename T>
+int upload(dvsg_locnet *net, const std::vector<T> &h, T **dev) {
   void *p = nullptr;
-  DVSG_HIP(hipMalloc(&p, h.size() * sizeof(float)));
+  DVSG_HIP(hipMalloc(&p, h.size() * sizeof(T)));
   net->allocs.push_back(p);
-  DVSG_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-  *dev = static_cast<float *>(p);
+  DVSG_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dev = static_cast<T *>(p);
   return DVSG_OK;
 }
 
@@ -113,7 +117,7 @@ int bn_fold(const ArrayMap &m, const std::string &scope, int c, std::vector<floa
   return DVSG_OK;
 }
 
-// Generic conv: HWIO -> [cout][kh][kw][cin] with the BN scale folded in.
+// Generic conv: HWIO -> [cout][kh][kw][cin] with the BN scale folded in; float32 and float16 copies.
 int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, ConvLayer *L) {
   const HostArray *w;
   if (int rc = find(m, scope + "/weights", {L->ksize, L->ksize, L->cin, L->cout}, &w)) return rc;
@@ -123,7 +127,10 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
   std::vector<float> wt((size_t)L->cout * K);
   for (int k = 0; k < K; ++k)
     for (int n = 0; n < L->cout; ++n) wt[(size_t)n * K + k] = w->data[(size_t)k * L->cout + n] * scale[n];
+  std::vector<_Float16> wt16(wt.size());
+  for (size_t i = 0; i < wt.size(); ++i) wt16[i] = (_Float16)wt[i];
   if (int rc = upload(net, wt, &L->wt)) return rc;
+  if (int rc = upload(net, wt16, &L->wt16)) return rc;
   return upload(net, shift, &L->bias);
 }
 
@@ -168,10 +175,12 @@ Dims root_dims(int H, int W) {
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Workspace {
-  float *bufA, *bufB, *bufS, *r1, *r2, *pool_part, *dpart0, *dpart1, *T, *Ft;
+  char *bufA, *bufB, *bufS, *r1, *r2;  // activations (element type = the run's precision)
+  float *pool_part, *dpart0, *dpart1, *T, *Ft;
   size_t total;
 };
 
+// Sized for float32 activations; the float16 run uses the same plan with half the bytes.
 Workspace plan(char *base, int B, int H, int W) {
   const Dims d = root_dims(H, W);
   const size_t big = align256((size_t)B * d.Hp * d.Wp * 256 * sizeof(float));
@@ -181,26 +190,27 @@ Workspace plan(char *base, int B, int H, int W) {
   auto take = [&](size_t bytes) {
     char *p = base + off;
     off += align256(bytes);
-    return reinterpret_cast<float *>(p);
+    return p;
   };
   w.bufA = take(big);
   w.bufB = take(big);
   w.bufS = take(big);
   w.r1 = take(small);
   w.r2 = take(small);
-  w.pool_part = take((size_t)kPoolSplits * B * 2048 * sizeof(float));
-  w.dpart0 = take((size_t)kDenseSplits * 16 * 2048 * sizeof(float));
-  w.dpart1 = take((size_t)kDenseSplits * 16 * 2048 * sizeof(float));
-  w.T = take((size_t)B * 2 * 28 * sizeof(float));
-  w.Ft = take((size_t)B * 50 * sizeof(float));
+  w.pool_part = reinterpret_cast<float *>(take((size_t)kPoolSplits * B * 2048 * sizeof(float)));
+  w.dpart0 = reinterpret_cast<float *>(take((size_t)kDenseSplits * 16 * 2048 * sizeof(float)));
+  w.dpart1 = reinterpret_cast<float *>(take((size_t)kDenseSplits * 16 * 2048 * sizeof(float)));
+  w.T = reinterpret_cast<float *>(take((size_t)B * 2 * 28 * sizeof(float)));
+  w.Ft = reinterpret_cast<float *>(take((size_t)B * 50 * sizeof(float)));
   w.total = off;
   return w;
 }
 
-int run_conv(const ConvLayer &L, const float *x, int B, int H, int W, float *y, int Ho, int Wo, const float *res,
-             int res_H, int res_W, int res_stride, bool relu, hipStream_t s) {
+int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, void *y, int Ho, int Wo,
+             const void *res, int res_H, int res_W, int res_stride, bool relu, hipStream_t s) {
   ConvGemm p;
-  p.x = x; p.wt = L.wt; p.bias = L.bias; p.res = res; p.y = y;
+  p.prec = prec;
+  p.x = x; p.wt = L.weights(prec); p.bias = L.bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
   p.res_H = res_H; p.res_W = res_W; p.res_stride = res_stride;
@@ -208,8 +218,8 @@ int run_conv(const ConvLayer &L, const float *x, int B, int H, int W, float *y, 
   return launch_conv_gemm(p, s);
 }
 
-// Runs the network; stop_stage < 0 runs everything and writes F_t [B,50].
-int forward(const dvsg_locnet *net, const float *patches, int B, int H, int W, float *F_t, int stop_stage,
+// Runs the network in precision `prec`; stop_stage < 0 runs everything and writes F_t [B,50].
+int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H, int W, float *F_t, int stop_stage,
             float *act_out, size_t act_out_bytes, int *act_dims, void *workspace, size_t workspace_bytes,
             hipStream_t s) {
   DVSG_REQUIRE(net && patches && workspace, "locnet forward: NULL pointer");
@@ -220,11 +230,17 @@ int forward(const dvsg_locnet *net, const float *patches, int B, int H, int W, f
     return fail(DVSG_ERR_WORKSPACE, "locnet forward: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
   const Dims d = root_dims(H, W);
 
-  auto tap = [&](int stage, const float *act, int h, int w, int c) -> int {
+  // parity tap: copy (float32 run) or convert (float16 run) the stage's activation to act_out
+  auto tap = [&](int stage, const void *act, int h, int w, int c) -> int {
     if (stage != stop_stage) return 0;
-    const size_t bytes = (size_t)B * h * w * c * sizeof(float);
-    if (bytes > act_out_bytes) return fail(DVSG_ERR_INVALID_ARG, "tap buffer %zu bytes < %zu", act_out_bytes, bytes);
-    DVSG_HIP(hipMemcpyAsync(act_out, act, bytes, hipMemcpyDeviceToDevice, s));
+    const size_t n = (size_t)B * h * w * c;
+    if (n * sizeof(float) > act_out_bytes)
+      return fail(DVSG_ERR_INVALID_ARG, "tap buffer %zu bytes < %zu", act_out_bytes, n * sizeof(float));
+    if (prec == kF16) {
+      if (int rc = launch_f16_to_f32(act, act_out, n, s)) return rc;
+    } else {
+      DVSG_HIP(hipMemcpyAsync(act_out, act, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     act_dims[0] = h; act_dims[1] = w; act_dims[2] = c;
     return 1;
   };
@@ -239,36 +255,36 @@ int forward(const dvsg_locnet *net, const float *patches, int B, int H, int W, f
     if (int rc_ = (call)) return rc_; \
   } while (0)
 
-  // root: conv1 (+ fused scale_RGB) -> bufA, max pool -> bufB
-  DVSG_RUN(launch_conv1(patches, net->conv1.wt, net->conv1.bias, ws.bufA, B, H, W, d.H1, d.W1, s));
+  // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
+  DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.bias, ws.bufA, B, H, W, d.H1, d.W1, s));
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
-  DVSG_RUN(launch_maxpool(ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
+  DVSG_RUN(launch_maxpool(prec, ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
   DVSG_TAP(1, ws.bufB, d.Hp, d.Wp, 64);
 
-  float *X = ws.bufB, *Y = ws.bufA;
+  char *X = ws.bufB, *Y = ws.bufA;
   int h = d.Hp, w = d.Wp;
   int stage = 2;
   for (const Unit &u : net->units) {
     const int ho = (h - 1) / u.stride + 1, wo = (w - 1) / u.stride + 1;
-    const float *res = X;
+    const void *res = X;
     int res_h = h, res_w = w, res_stride = u.stride;
     if (u.has_shortcut) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
-      DVSG_RUN(run_conv(u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, s));
+      DVSG_RUN(run_conv(prec, u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, s));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
     }
-    DVSG_RUN(run_conv(u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, s));
-    DVSG_RUN(run_conv(u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, s));
-    DVSG_RUN(run_conv(u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, s));
+    DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, s));
+    DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, s));
+    DVSG_RUN(run_conv(prec, u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, s));
     h = ho; w = wo;
     DVSG_TAP(stage, Y, h, w, u.depth);
     ++stage;
-    float *tmp = X; X = Y; Y = tmp;
+    char *tmp = X; X = Y; Y = tmp;
   }
 
-  // global average pool (partial sums), then the dense head in chunks of <= 16 samples;
-  // partial layouts are [b][split][k] so a batch chunk is a pointer offset.
-  DVSG_RUN(launch_avgpool_partial(X, ws.pool_part, B, h * w, 2048, s));
+  // global average pool (float32 partial sums), then the float32 dense head in chunks of <= 16
+  // samples; partial layouts are [b][split][k] so a batch chunk is a pointer offset.
+  DVSG_RUN(launch_avgpool_partial(prec, X, ws.pool_part, B, h * w, 2048, s));
   const float inv_hw = 1.0f / (float)(h * w);
   if (stop_stage == 18) {
     const size_t bytes = (size_t)B * 2048 * sizeof(float);
@@ -290,6 +306,39 @@ int forward(const dvsg_locnet *net, const float *patches, int B, int H, int W, f
   return DVSG_OK;
 #undef DVSG_TAP
 #undef DVSG_RUN
+}
+
+int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const float *u_t, int B, int H, int W,
+              float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
+              void *stream) {
+  DVSG_REQUIRE(net && patches_t && u_t && s_t_pred && workspace, "dvsg_stabilize: NULL pointer");
+  DVSG_REQUIRE(B > 0 && B <= 65535, "dvsg_stabilize: B=%d out of range", B);
+  const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
+  if (ws.total > workspace_bytes)
+    return fail(DVSG_ERR_WORKSPACE, "dvsg_stabilize: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
+  float *F = F_t ? F_t : ws.Ft;
+  if (int rc = forward(net, prec, patches_t, B, H, W, F, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
+                       as_stream(stream)))
+    return rc;
+  // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111); float32
+  if (int rc = tps_solve_impl(net->v_src, 0, F, 1, B, 25, ws.T, stream)) return rc;
+  return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
+}
+
+int conv_gemm_op(int prec, const void *x, const void *wt, const float *bias, const void *res, void *y, int B, int H,
+                 int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
+  DVSG_REQUIRE(x && wt && bias && y, "dvsg_conv_gemm: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && res_stride >= 1, "dvsg_conv_gemm: bad shape");
+  ConvGemm p;
+  p.prec = prec;
+  p.x = x; p.wt = wt; p.bias = bias; p.res = res; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = ksize == 3 ? 1 : 0;
+  p.res_H = (p.Ho - 1) * res_stride + 1; p.res_W = (p.Wo - 1) * res_stride + 1;
+  p.res_stride = res_stride;
+  p.relu = relu;
+  return launch_conv_gemm(p, as_stream(stream));
 }
 
 }  // namespace
@@ -392,7 +441,15 @@ int dvsg_locnet_workspace_bytes(const dvsg_locnet_t *net, int B, int H, int W, s
 int dvsg_locnet_forward_f32(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, float *F_t,
                             void *workspace, size_t workspace_bytes, void *stream) {
   DVSG_REQUIRE(F_t, "dvsg_locnet_forward_f32: NULL F_t");
-  return forward(net, patches, B, H, W, F_t, -1, nullptr, 0, nullptr, workspace, workspace_bytes, as_stream(stream));
+  return forward(net, kF32, patches, B, H, W, F_t, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
+                 as_stream(stream));
+}
+
+int dvsg_locnet_forward_f16(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, float *F_t,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(F_t, "dvsg_locnet_forward_f16: NULL F_t");
+  return forward(net, kF16, patches, B, H, W, F_t, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
+                 as_stream(stream));
 }
 
 int dvsg_locnet_forward_tap_f32(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
@@ -400,24 +457,27 @@ int dvsg_locnet_forward_tap_f32(const dvsg_locnet_t *net, const float *patches, 
                                 size_t workspace_bytes, void *stream) {
   DVSG_REQUIRE(act_out && act_dims_host, "dvsg_locnet_forward_tap_f32: NULL pointer");
   DVSG_REQUIRE(stage >= 0 && stage <= 18, "dvsg_locnet_forward_tap_f32: stage %d outside [0,18]", stage);
-  return forward(net, patches, B, H, W, nullptr, stage, act_out, act_out_bytes, act_dims_host, workspace,
+  return forward(net, kF32, patches, B, H, W, nullptr, stage, act_out, act_out_bytes, act_dims_host, workspace,
+                 workspace_bytes, as_stream(stream));
+}
+
+int dvsg_locnet_forward_tap_f16(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
+                                float *act_out, size_t act_out_bytes, int *act_dims_host, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(act_out && act_dims_host, "dvsg_locnet_forward_tap_f16: NULL pointer");
+  DVSG_REQUIRE(stage >= 0 && stage <= 18, "dvsg_locnet_forward_tap_f16: stage %d outside [0,18]", stage);
+  return forward(net, kF16, patches, B, H, W, nullptr, stage, act_out, act_out_bytes, act_dims_host, workspace,
                  workspace_bytes, as_stream(stream));
 }
 
 int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y, int B, int H,
                        int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
-  DVSG_REQUIRE(x && wt && bias && y, "dvsg_conv_gemm_f32: NULL pointer");
-  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && res_stride >= 1, "dvsg_conv_gemm_f32: bad shape");
-  ConvGemm p;
-  p.x = x; p.wt = wt; p.bias = bias; p.res = res; p.y = y;
-  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
-  p.ksize = ksize; p.stride = stride; p.pad = ksize == 3 ? 1 : 0;
-  p.res_H = p.Ho * res_stride - (res_stride - 1); p.res_W = p.Wo * res_stride - (res_stride - 1);
-  p.res_stride = res_stride;
-  if (res && res_stride == 1) { p.res_H = p.Ho; p.res_W = p.Wo; }
-  p.relu = relu;
-  return launch_conv_gemm(p, as_stream(stream));
+  return conv_gemm_op(kF32, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, stream);
+}
+
+int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y, int B, int H,
+                       int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
+  return conv_gemm_op(kF16, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, stream);
 }
 
 int dvsg_debug_set_option(const char *name, int value) {
@@ -436,17 +496,13 @@ int dvsg_debug_set_option(const char *name, int value) {
 int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                        void *stream) {
-  DVSG_REQUIRE(net && patches_t && u_t && s_t_pred && workspace, "dvsg_stabilize_f32: NULL pointer");
-  DVSG_REQUIRE(B > 0 && B <= 65535, "dvsg_stabilize_f32: B=%d out of range", B);
-  const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
-  if (ws.total > workspace_bytes)
-    return fail(DVSG_ERR_WORKSPACE, "dvsg_stabilize_f32: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
-  float *F = F_t ? F_t : ws.Ft;
-  if (int rc = forward(net, patches_t, B, H, W, F, -1, nullptr, 0, nullptr, workspace, workspace_bytes, as_stream(stream)))
-    return rc;
-  // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111)
-  if (int rc = tps_solve_impl(net->v_src, 0, F, 1, B, 25, ws.T, stream)) return rc;
-  return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
+  return stabilize(net, kF32, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+}
+
+int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
+                       float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+  return stabilize(net, kF16, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -63,6 +63,7 @@ class StabNet:
         self.param_dim = self.num_control_points ** 2
         self.stabNet_model = 'resnet_v1_50'
         self.n_streams = 1   # 2 = batch halves on two HIP streams (LocNet.stabilize): +4 % at B=16 720p
+        self.precision = "f32"   # "f16": float16 activations / conv weights in localizationNet
         self.locnet = None
         self.inputs = None
         self.outputs = None
@@ -122,13 +123,13 @@ class StabNet:
             want_xy = 'x_offset_t' in keys or 'y_offset_t' in keys
             xs = empty((B * H * W,), u_t) if want_xy else None
             ys = empty((B * H * W,), u_t) if want_xy else None
-            self.locnet.stabilize(patches, u_t, out, F, xs, ys, n_streams=self.n_streams)
+            self.locnet.stabilize(patches, u_t, out, F, xs, ys, n_streams=self.n_streams, precision=self.precision)
             vals.update(F_t=F, s_t_pred=out, x_offset_t=xs, y_offset_t=ys)
             if 's_t_pred_mask' in keys:  # model.py:121
                 V = torch.from_numpy(V_SRC).to(u_t.device).unsqueeze(0).repeat(B, 1, 1)
                 vals['s_t_pred_mask'], _, _ = stn(torch.ones_like(u_t), V, F, [self.h, self.w])
         elif 'F_t' in keys:
-            vals['F_t'] = self.locnet.forward(patches, self.param_dim)
+            vals['F_t'] = self.locnet.forward(patches, self.param_dim, precision=self.precision)
         return vals
 
 

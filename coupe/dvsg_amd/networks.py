@@ -26,6 +26,14 @@ def scale_RGB(rgb):
     return like_input(out, rgb)
 
 
+def _entry(base, precision):
+    """C entry point for a storage precision: "f32" (exact float32 matrix cores, the reference's
+    arithmetic) or "f16" (float16 activations / conv weights, float32 accumulation)."""
+    if precision not in ("f32", "f16"):
+        raise ValueError("precision must be 'f32' or 'f16', got %r" % (precision,))
+    return "%s_%s" % (base, precision)
+
+
 class LocNet(object):
     """Owns the device-side network (`dvsg_locnet_t`) and a growable workspace."""
 
@@ -69,17 +77,18 @@ class LocNet(object):
             ws = self._ws[slot] = torch.empty(need.value, dtype=torch.uint8, device=device())
         return ws, need.value
 
-    def stabilize(self, patches, u_t, out, F, xs=None, ys=None, n_streams=1):
+    def stabilize(self, patches, u_t, out, F, xs=None, ys=None, n_streams=1, precision="f32"):
         """`dvsg_stabilize_f32` on device tensors, optionally with the batch split over
         `n_streams` side streams: every conv launch covers the chip in a few rounds of tiles and
         its last round is only partly full; launches from two independent half batches fill each
         other's tails (+4 % at B=16 720p).  Results do not depend on the split (samples are
         independent); the caller's stream sees one fork / join."""
         import torch
+        fn = _entry("dvsg_stabilize", precision)
         B, H, W, _ = u_t.shape
         if n_streams <= 1 or B < 2 * n_streams:
             ws, nbytes = self.workspace(B, H, W)
-            _lib.call("dvsg_stabilize_f32", self.handle, ptr(patches), ptr(u_t), B, H, W, ptr(out), ptr(F),
+            _lib.call(fn, self.handle, ptr(patches), ptr(u_t), B, H, W, ptr(out), ptr(F),
                       ptr(xs), ptr(ys), ptr(ws), nbytes, stream())
             return
         if getattr(self, "_side", None) is None or len(self._side) != n_streams:
@@ -94,14 +103,14 @@ class LocNet(object):
                 break
             side.wait_event(fork)
             ws, nbytes = self.workspace(b1 - b0, H, W, slot=1 + i)
-            _lib.call("dvsg_stabilize_f32", self.handle, ptr(patches[b0:b1]), ptr(u_t[b0:b1]), b1 - b0, H, W,
+            _lib.call(fn, self.handle, ptr(patches[b0:b1]), ptr(u_t[b0:b1]), b1 - b0, H, W,
                       ptr(out[b0:b1]), ptr(F[b0:b1]), ptr(xs[b0 * H * W:b1 * H * W]) if xs is not None else 0,
                       ptr(ys[b0 * H * W:b1 * H * W]) if ys is not None else 0, ptr(ws), nbytes, side.cuda_stream)
             join = torch.cuda.Event()
             join.record(side)
             cur.wait_event(join)
 
-    def forward(self, patches, param_dim=25):
+    def forward(self, patches, param_dim=25, precision="f32"):
         t = as_dev(patches)
         B, H, W, C = t.shape
         if C != self.in_channels:
@@ -110,11 +119,12 @@ class LocNet(object):
             raise ValueError("the reference's dense4 has 50 outputs: param_dim must be 25")
         ws, nbytes = self.workspace(B, H, W)
         F = empty((B, param_dim, 2), t)
-        _lib.call("dvsg_locnet_forward_f32", self.handle, ptr(t), B, H, W, ptr(F), ptr(ws), nbytes, stream())
+        _lib.call(_entry("dvsg_locnet_forward", precision), self.handle, ptr(t), B, H, W, ptr(F), ptr(ws), nbytes,
+                  stream())
         return F
 
-    def tap(self, patches, stage):
-        """Parity hook: activation after `stage` (0 conv1, 1 pool1, 2..17 units, 18 pool5)."""
+    def tap(self, patches, stage, precision="f32"):
+        """Parity hook: activation after `stage` (0 conv1, 1 pool1, 2..17 units, 18 pool5), float32."""
         t = as_dev(patches)
         B, H, W, C = t.shape
         ws, nbytes = self.workspace(B, H, W)
@@ -122,7 +132,7 @@ class LocNet(object):
         cap = B * max(h1 * w1 * 64, ((h1 + 1) // 2) * ((w1 + 1) // 2) * 256)
         buf = empty((cap,), t)
         dims = (ctypes.c_int * 3)()
-        _lib.call("dvsg_locnet_forward_tap_f32", self.handle, ptr(t), B, H, W, int(stage), ptr(buf), cap * 4,
+        _lib.call(_entry("dvsg_locnet_forward_tap", precision), self.handle, ptr(t), B, H, W, int(stage), ptr(buf), cap * 4,
                   dims, ptr(ws), nbytes, stream())
         h, w, c = dims[0], dims[1], dims[2]
         return buf[:B * h * w * c].reshape(B, h, w, c)

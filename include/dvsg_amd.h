@@ -161,7 +161,30 @@ int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                        int res_stride, void *stream);
 
-/* Diagnostic A/B switches for kernel experiments ("conv_variant").  Process-global. */
+/* ---------------------------------------------------------------------------------------
+ * float16 variants (BASELINE.json configs[4]: "fp16 MFMA convs").  Same arguments and the same
+ * float32 inputs / outputs as the _f32 entry points; inside, activations and conv weights are
+ * stored as float16 and the 1x1 / 3x3 convolutions run on v_mfma_f32_32x32x16_f16 with float32
+ * accumulation (conv1 multiplies the float32 frames in f32 and writes f16; BatchNorm shift,
+ * the dense head, the TPS solve and the warp stay float32).  Not bit-compatible with the
+ * float32 reference path: tests/test_gpu_f16.py states the measured F_t / pixel error.
+ * The workspace of dvsg_locnet_workspace_bytes is sufficient (half of it is used).
+ * ------------------------------------------------------------------------------------- */
+int dvsg_locnet_forward_f16(const dvsg_locnet_t *net, const float *patches, int B, int H, int W,
+                            float *F_t, void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_locnet_forward_tap_f16(const dvsg_locnet_t *net, const float *patches, int B, int H,
+                                int W, int stage, float *act_out, size_t act_out_bytes,
+                                int *act_dims_host, void *workspace, size_t workspace_bytes,
+                                void *stream);
+int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B,
+                       int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* x, wt, res, y are float16 (Cin % 64 == 0); bias float32. */
+int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y,
+                       int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                       int res_stride, void *stream);
+
+/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant").  Process-global. */
 int dvsg_debug_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------

@@ -1,0 +1,136 @@
+"""GPU parity at BASELINE.json's full sizes (1280x720, B=16 / B=64; one 3840x2160 frame), where
+the NumPy oracle is too slow to run on every pixel of every sample: size-independent properties
+(identity, integer shifts, linearity, batch invariance, run-to-run determinism) plus spot checks
+of single samples against the oracle."""
+import numpy as np
+import pytest
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+H, W = 720, 1280
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _frames(dev, B, h=H, w=W, c=3, seed=0):
+    import torch
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.rand((B, h, w, c), generator=g, device=dev)
+
+
+def test_tf_warp_b64_720p_properties(dev):
+    """configs[2]: identity, integer shift, linearity in the image, one sample vs the oracle."""
+    import torch
+    from coupe.dvsg_amd.warp_with_optical_flow import tf_warp
+    from oracle.warp_with_optical_flow import tf_warp as o_warp
+    B = 64
+    im = _frames(dev, B)
+    zero = torch.zeros((B, H, W, 2), device=dev)
+    assert torch.equal(tf_warp(im, zero, H, W), im)
+    sh = zero.clone()
+    sh[..., 0] = 5.0
+    sh[..., 1] = -3.0
+    out = tf_warp(im, sh, H, W)
+    assert torch.equal(out[:, 3:, :W - 5], im[:, :H - 3, 5:])
+    assert float(out[:, :3].abs().max()) == 0.0 and float(out[:, :, W - 5:].abs().max()) == 0.0
+    flow = torch.from_numpy(inputs.smooth_flow(7, 1, H, W)).to(dev).repeat(B, 1, 1, 1)
+    a = tf_warp(im, flow, H, W)
+    im2 = _frames(dev, B, seed=1)
+    b = tf_warp(im2, flow, H, W)
+    ab = tf_warp(0.25 * im + 0.5 * im2, flow, H, W)
+    assert float((ab - (0.25 * a + 0.5 * b)).abs().max()) < 1e-6          # linear in the image
+    ref = o_warp(im[5:6].cpu().numpy(), flow[5:6].cpu().numpy(), H, W)
+    assert np.abs(a[5:6].cpu().numpy() - ref).max() <= 1e-6
+
+
+def test_tps_b16_720p_properties(dev):
+    """configs[1] warp stage: zero / uniform control vectors, per-sample independence, and one
+    sample against the oracle at full resolution."""
+    import torch
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
+    from oracle import thin_plate_spline as otps
+    B = 16
+    U = torch.from_numpy(inputs.smooth_frames(3, 2, H, W)).to(dev).repeat(8, 1, 1, 1)
+    coord = torch.from_numpy(inputs.v_src(B)).to(dev)
+    _, x, y = ThinPlateSpline(U, coord, torch.zeros_like(coord), (H, W))
+    xt = torch.linspace(-1, 1, W, device=dev).repeat(H)
+    yt = torch.linspace(-1, 1, H, device=dev).repeat_interleave(W)
+    assert float((x.reshape(B, -1) - xt).abs().max()) < 5e-6 and float((y.reshape(B, -1) - yt).abs().max()) < 5e-6
+    vec = torch.from_numpy(inputs.control_vectors(4, B)).to(dev)
+    out, x, y = ThinPlateSpline(U, coord, vec, (H, W))
+    out1, x1, y1 = ThinPlateSpline(U[9:10], coord[9:10], vec[9:10], (H, W))
+    assert torch.equal(out[9:10], out1) and torch.equal(x.reshape(B, -1)[9], x1)   # batch invariance
+    ro, rx, ry = otps.ThinPlateSpline(U[9:10].cpu().numpy(), coord[9:10].cpu().numpy(), vec[9:10].cpu().numpy(), (H, W))
+    gerr = max(np.abs(x1.cpu().numpy() - rx).max() * W / 2, np.abs(y1.cpu().numpy() - ry).max() * H / 2)
+    assert gerr < 2e-2, "grid error %.3g px" % gerr
+    mask = otps.border_discontinuity_mask(rx, ry, H, W, delta=3e-2).reshape(1, H, W)
+    err = np.abs(out1.cpu().numpy() - ro).max(axis=3)
+    assert err[~mask].max() < 1e-3          # BASELINE.json: warped-frame max abs error < 1e-3
+    assert mask.mean() < 0.01
+
+
+def test_locnet_b16_720p(dev, synthetic_weights):
+    """configs[1] CNN stage: batch invariance, bitwise run-to-run determinism, and two of the 16
+    windows against the (torch-CPU) oracle at 720p."""
+    import torch
+    from coupe.dvsg_amd.networks import LocNet
+    from oracle.cnn_torch import TorchLocNet
+    B = 16
+    net = LocNet(synthetic_weights)
+    x = torch.from_numpy(inputs.window_frames(5, 2, H, W)).to(dev)
+    x = torch.cat([x, x.flip(0)] * 4, 0)                  # 16 windows, two distinct ones
+    F = net.forward(x)
+    assert torch.equal(F, net.forward(x))                 # deterministic (no atomics anywhere)
+    assert torch.equal(F[0], F[3]) and torch.equal(F[1], F[2]) and torch.equal(F[0], F[15])
+    F1 = net.forward(x[1:2])
+    assert float((F1 - F[1:2]).abs().max()) <= 1e-6       # independent of the batch around it
+    ref = TorchLocNet(synthetic_weights).forward(x[:2].cpu().numpy())
+    assert np.abs(F[:2].cpu().numpy() - ref).max() <= 1e-5
+
+
+def test_stabilize_single_4k_frame(dev, synthetic_weights):
+    """One 3840x2160 window (configs[4] resolution, float32): F_t against the torch-CPU oracle and
+    the identity-warp property; exercises every kernel at sizes 9x the 720p case."""
+    import torch
+    from coupe.dvsg_amd.model import Session, StabNet
+    from oracle.cnn_torch import TorchLocNet
+    h, w = 2160, 3840
+    x = torch.from_numpy(inputs.window_frames(9, 1, h // 8, w // 8)).to(dev)
+    x = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(h, w), mode="bilinear",
+                                        align_corners=False).permute(0, 2, 3, 1).contiguous()
+    model = StabNet(h, w).load_weights(synthetic_weights)
+    ins, outs = model.get_evaluation_model(7)
+    s_t_pred, F = Session().run([outs["s_t_pred"], outs["F_t"]], {ins["patches_t"]: x, ins["u_t"]: x[..., 18:].contiguous()})
+    ref = TorchLocNet(synthetic_weights).forward(x.cpu().numpy())
+    assert np.abs(F.cpu().numpy() - ref).max() <= 2e-5
+    assert s_t_pred.shape == (1, h, w, 3) and bool(torch.isfinite(s_t_pred).all())
+    # sampler A's out-of-range taps cancel only up to rounding (weights of coincident taps, x ~ 4e3)
+    assert -1e-4 <= float(s_t_pred.min()) and float(s_t_pred.max()) <= 1.0 + 1e-4
+
+
+def test_stream_split_is_invisible(dev, synthetic_weights):
+    """LocNet.stabilize with the batch split over two HIP streams returns bit-identical results."""
+    import torch
+    from coupe.dvsg_amd.networks import LocNet
+    B, h, w = 6, 96, 160
+    net = LocNet(synthetic_weights)
+    x = torch.from_numpy(inputs.window_frames(11, B, h, w)).to(dev)
+    u = x[..., 18:].contiguous()
+    res = []
+    for n in (1, 2, 3):
+        out = torch.empty((B, h, w, 3), device=dev)
+        F = torch.empty((B, 25, 2), device=dev)
+        xs = torch.empty((B * h * w,), device=dev)
+        ys = torch.empty_like(xs)
+        net.stabilize(x, u, out, F, xs, ys, n_streams=n)
+        torch.cuda.synchronize()
+        res.append((out, F, xs, ys))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--variants", default="1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", default="uniq")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dev = torch.device("cuda:0")
@@ -60,19 +61,20 @@ def main():
           " | ".join("v%d: us    TF/s  TB/s" % v for v in variants))
     for name, h, w, cin, cout, k, stride, relu, has_res in shapes:
         ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-        x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
+        dt = torch.float16 if args.precision == "f16" else torch.float32
+        x = (torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3).to(dt)
         K = k * k * cin
-        wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
+        wt = ((torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)).to(dt)
         bias = torch.rand((cout,), generator=g, device=dev) - 0.5
-        res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5) if has_res else None
-        y = torch.empty((B, ho, wo, cout), device=dev)
+        res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5).to(dt) if has_res else None
+        y = torch.empty((B, ho, wo, cout), device=dev, dtype=dt)
         M = B * ho * wo
         flops = 2.0 * M * cout * K
-        nbytes = 4.0 * (x.numel() + wt.numel() + y.numel() * (2 if has_res else 1))
+        nbytes = x.element_size() * (x.numel() + wt.numel() + y.numel() * (2 if has_res else 1))
         times = {v: [] for v in variants}
 
         def run():
-            _lib.call("dvsg_conv_gemm_f32", x.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+            _lib.call("dvsg_conv_gemm_" + args.precision, x.data_ptr(), wt.data_ptr(), bias.data_ptr(),
                       res.data_ptr() if has_res else 0, y.data_ptr(), B, h, w, cin, cout, k, stride, int(relu), 1,
                       stream)
         for rnd in range(args.rounds + 1):
