@@ -90,6 +90,31 @@ class StabNet:
         self.inputs, self.outputs = inputs, outputs
         return inputs, outputs
 
+    # -- eval_train.py's occlusion mask (model.py:156-167) ----------------------------------
+    def random_mask(self, patches, out_size, sample_num, H=None, generator=None):
+        """model.py:156-167: a ones mask over the history frames (first 3*(sample_num-1) channels)
+        is warped by a random near-identity homography (zeros enter from outside the frame) and
+        multiplies the window; the current frame's 3 channels are never masked.  The reference
+        draws H with tf.random_uniform inside the graph; pass `H` [B,8] to make it reproducible
+        (or a torch `generator`).  Returns (patches * mask, mask)."""
+        from .spatial_transformer import ProjectiveTransformer
+        p = as_dev(patches)
+        B = p.shape[0]
+        c_hist = 3 * (sample_num - 1)
+        if H is None:
+            gdev = p.device if generator is None else generator.device
+            u = torch.rand((B, 8), generator=generator, device=gdev).to(p.device) * 2.0 - 1.0       # :161
+            Ht = u * torch.tensor([0.1, 0.1, 0.5, 0.1, 0.1, 0.5, 0.1, 0.1], device=p.device)       # :162
+            Ht = Ht + torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], device=p.device)      # :163
+        else:
+            Ht = as_dev(H).reshape(B, 8)
+        mask = ProjectiveTransformer(out_size).transform(torch.ones_like(p[..., :c_hist]).contiguous(), Ht)  # :164
+        mask = torch.cat([mask, torch.ones_like(p[..., :3])], dim=3)                                # :165
+        out = p * mask
+        if is_host(patches):
+            return out.cpu().numpy(), mask.cpu().numpy()
+        return out, mask
+
     # -- execution --------------------------------------------------------------------------
     def _execute(self, keys, feed):
         if self.locnet is None:

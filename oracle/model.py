@@ -48,6 +48,18 @@ class StabNet:
         return [out[k] for k in fetch]
 
 
+def random_mask(patches, out_size, sample_num, H):
+    """model.py:156-167 with the homography parameters H [B,8] supplied by the caller (the reference
+    draws them with tf.random_uniform and applies the scale / identity offset of lines 162-163)."""
+    from .spatial_transformer import ProjectiveTransformer
+    patches = np.asarray(patches, dtype=F32)
+    c_hist = 3 * (sample_num - 1)
+    mask = np.ones_like(patches[..., :c_hist])                                   # :160
+    mask = ProjectiveTransformer(out_size).transform(mask, np.asarray(H, F32))    # :164
+    mask = np.concatenate([mask, np.ones_like(patches[..., :3])], axis=3)        # :165
+    return (patches * mask).astype(F32), mask.astype(F32)                        # :167
+
+
 def eval_clip(weights, frames, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32)):
     """eval.py:93-124 on an in-memory clip ``frames`` [N,h,w,3] float (already RGB, /255,
     resized: eval.py:76-81 is cv2 I/O and out of scope).

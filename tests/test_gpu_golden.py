@@ -65,3 +65,20 @@ def test_eval_clip_loop(synthetic_weights):
     assert np.array_equal(side[:, :, :W], rside[:, :, :W])      # left half: the unstable input
     diff = np.abs(side[:, :, W:].astype(int) - rside[:, :, W:].astype(int))
     assert (diff > 1).mean() < 0.01
+
+
+def test_random_mask_matches_oracle(synthetic_weights):
+    """eval_train.py's occlusion mask (model.py:156-167) with an explicit homography."""
+    from coupe.dvsg_amd.model import StabNet
+    B, H, W = 2, 40, 64
+    x = inputs.window_frames(4001, B, H, W)
+    rng = np.random.default_rng(4002)
+    Hm = rng.uniform(-1, 1, (B, 8)) * np.array([0.1, 0.1, 0.5, 0.1, 0.1, 0.5, 0.1, 0.1])
+    Hm = (Hm + np.array([1.0, 0, 0, 0, 1.0, 0, 0, 0])).astype(np.float32)
+    got, mask = StabNet(H, W).random_mask(x, (H, W), 7, H=Hm)
+    ref, rmask = omodel.random_mask(x, (H, W), 7, Hm)
+    assert mask.shape == (B, H, W, 21) and np.all(mask[..., 18:] == 1.0)
+    assert np.abs(mask - rmask).max() <= 5e-5 and np.abs(got - ref).max() <= 5e-5
+    assert 0.0 < (mask[..., :18] < 0.5).mean() < 0.6      # part of the history is really occluded
+    got2, mask2 = StabNet(H, W).random_mask(x, (H, W), 7)   # stochastic form, as in the reference
+    assert mask2.shape == mask.shape and np.all(mask2[..., 18:] == 1.0)
