@@ -40,8 +40,8 @@ SIGNATURES = {
     "dvsg_locnet_forward_tap_f16": [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t,
                                     ctypes.POINTER(_i), _vp, ctypes.c_size_t, _vp],
     "dvsg_stabilize_f16": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
-    "dvsg_conv_gemm_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "dvsg_conv_gemm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "dvsg_conv_gemm_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
+    "dvsg_conv_gemm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_debug_set_option": [ctypes.c_char_p, _i],
     "dvsg_prof_begin": [_i],
     "dvsg_prof_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double),

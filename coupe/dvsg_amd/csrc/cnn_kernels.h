@@ -28,7 +28,13 @@ struct ConvGemm {
   int ksize, stride, pad;
   int res_H, res_W, res_stride;
   int relu;
+  // optional split-K scratch (small batches): partial-tile slabs and kSplitKMaxTiles zeroed int tickets
+  void *splitk_scratch = nullptr;
+  size_t splitk_scratch_bytes = 0;
+  int *splitk_counters = nullptr;
 };
+constexpr int kSplitKMaxTiles = 256;                                   // tickets one launch may use
+constexpr size_t kSplitKSlabBytes = (size_t)512 * 128 * 64 * 4;        // 16 MiB: <= 512 slices of 128x64 f32
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
 void set_conv_variant(int v);   // diagnostic A/B switches (dvsg_debug_set_option)
 void set_conv1_variant(int v);

@@ -25,6 +25,8 @@
 // Epilogue: a lane of the 32x32 C/D layout owns ONE output channel, which would mean 16 dword
 // stores (and residual loads) per MFMA block per lane; instead the accumulators are transposed
 // through the idle staging LDS so every thread moves 4 consecutive channels (float4 / 4 x f16).
+#include <algorithm>
+
 #include "cnn_device.h"
 #include "cnn_kernels.h"
 
@@ -41,13 +43,16 @@ struct ConvGemmDev {
   const void *x, *wt, *res;
   const float *bias;
   void *y;
+  float *slabs;    // split-K partial tiles [tile][slice][128][BN] (ksplit > 1)
+  int *counters;   // split-K arrival tickets, one per tile, zeroed before the launch
+  int ksplit;
   int H, W, Cin, Ho, Wo, Cout;
   int stride, pad;
   int res_H, res_W, res_stride;
   int M, K, mtiles, ntiles;
 };
 
-template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES>
+template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, bool SPLITK>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN / 2, WM * WN / 2)))
 void conv_gemm_kernel(ConvGemmDev p) {
   constexpr int NW = WM * WN;
@@ -72,7 +77,11 @@ void conv_gemm_kernel(ConvGemmDev p) {
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
-  const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  // split-K: the slices of one tile are adjacent logical ids (same XCD: the reducer reads its
+  // siblings' slabs out of its own L2)
+  const int logical = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * (SPLITK ? p.ksplit : 1));
+  const int tile = SPLITK ? logical / p.ksplit : logical;
+  const int slice = SPLITK ? logical - tile * p.ksplit : 0;
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
 
@@ -113,7 +122,19 @@ void conv_gemm_kernel(ConvGemmDev p) {
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
   // (kh, kw, c0) of the stage being issued advance incrementally: no integer division in the loop
-  int s_kh = 0, s_kw = 0, s_c0 = 0, s_k0 = 0;
+  const int KT_all = p.K / BKE;
+  const int kt0 = SPLITK ? (int)((long)slice * KT_all / p.ksplit) : 0;
+  const int kt1 = SPLITK ? (int)((long)(slice + 1) * KT_all / p.ksplit) : KT_all;
+  int s_kh = 0, s_kw = 0, s_c0 = 0, s_k0 = kt0 * BKE;
+  if (SPLITK) {
+    s_c0 = s_k0;
+    if (KS > 1) {
+      const int tap = s_k0 / p.Cin;
+      s_c0 = s_k0 - tap * p.Cin;
+      s_kh = tap / KS;
+      s_kw = tap - s_kh * KS;
+    }
+  }
   auto issue_stage = [&](int buf) __attribute__((always_inline)) {
     const T *xa = px + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
 #pragma unroll
@@ -167,7 +188,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
 
   // __syncthreads() carries the vmcnt(0) that retires the DMA of the next stage (and orders
   // everyone's reads of the buffer about to be refilled).
-  const int KT = p.K / BKE;
+  const int KT = kt1 - kt0;
   issue_stage(0);
   __syncthreads();
   for (int kt = 0; kt < KT - 1; ++kt) {
@@ -199,11 +220,46 @@ void conv_gemm_kernel(ConvGemmDev p) {
   const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
   const T *pres = static_cast<const T *>(p.res);
   T *py = static_cast<T *>(p.y);
+  const float *slab0 = nullptr;
+  if (SPLITK) {
+    // In-launch split-K reduction, last-arriver form (no block ever waits for another one):
+    // every slice publishes its raw partial tile, takes a ticket, and the slice that draws the
+    // last ticket sums all partials IN SLICE ORDER (bitwise reproducible) and runs the epilogue.
+    slab0 = p.slabs + (size_t)tile * p.ksplit * (BM * BN);
+    float *mine = const_cast<float *>(slab0) + (size_t)slice * (BM * BN);
+    for (int row = row0; row < BM; row += RSTEP)
+      *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
+    __shared__ int s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != p.ksplit - 1) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
 #pragma unroll 4
   for (int row = row0; row < BM; row += RSTEP) {
     const int m = m0 + row;
     if (m >= p.M) break;
-    float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
+    float4 v;
+    if (SPLITK) {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sl = 0; sl < p.ksplit; ++sl) {
+        const float4 t = sl == slice ? *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4)
+                                     : *reinterpret_cast<const float4 *>(slab0 + ((size_t)sl * BM + row) * BN + 4 * col4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+    } else {
+      v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
+    }
     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
     if (RES != 0) {
       size_t roff;
@@ -228,10 +284,11 @@ void conv_gemm_kernel(ConvGemmDev p) {
 
 int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = by tile count, 1 = 4 waves, 2 = 8 waves
 
-template <typename T, int BN, int WM, int WN, int KS>
+template <typename T, int BN, int WM, int WN, int KS, bool SPLITK>
 int launch_cfg(const ConvGemmDev &d, bool relu, int res, hipStream_t s) {
-  const dim3 grid(d.mtiles * d.ntiles), block(64 * WM * WN);
-#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q>), grid, block, 0, s, d)
+  const dim3 grid(d.mtiles * d.ntiles * (SPLITK ? d.ksplit : 1)), block(64 * WM * WN);
+#define DVSG_LAUNCH(R, Q) \
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, SPLITK>), grid, block, 0, s, d)
   if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
@@ -250,10 +307,13 @@ int launch_ks(const ConvGemmDev &d, bool wide, bool relu, int res, hipStream_t s
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
   // waves in flight.
+  if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
+    return launch_cfg<T, 64, 2, 2, KS, true>(d, relu, res, s);
   const bool four = g_conv_variant == 1 || (g_conv_variant == 0 && (long)d.mtiles * d.ntiles <= 512);
   if (four)
-    return wide ? launch_cfg<T, 128, 2, 2, KS>(d, relu, res, s) : launch_cfg<T, 64, 2, 2, KS>(d, relu, res, s);
-  return wide ? launch_cfg<T, 128, 2, 4, KS>(d, relu, res, s) : launch_cfg<T, 64, 4, 2, KS>(d, relu, res, s);
+    return wide ? launch_cfg<T, 128, 2, 2, KS, false>(d, relu, res, s)
+                : launch_cfg<T, 64, 2, 2, KS, false>(d, relu, res, s);
+  return wide ? launch_cfg<T, 128, 2, 4, KS, false>(d, relu, res, s) : launch_cfg<T, 64, 4, 2, KS, false>(d, relu, res, s);
 }
 
 }  // namespace
@@ -285,6 +345,24 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide.
   const bool wide = p.Cout % 128 == 0 && (long)d.mtiles * (p.Cout / 128) >= 512;
   d.ntiles = p.Cout / (wide ? 128 : 64);
+  // Split-K when the launch has too few tiles for the 512 resident workgroups (batch 1-2): slices
+  // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
+  d.ksplit = 1;
+  d.slabs = nullptr;
+  d.counters = nullptr;
+  const long tiles = (long)d.mtiles * d.ntiles;
+  const int kt_all = d.K / bke;
+  // (measured at batch 1, 720p: pays for <= 128 tiles and K rows of >= 4 KiB, i.e. the 3x3 convs of
+  // blocks 3-4 and block 4's 1x1 convs; shorter K loops lose more to the reduction than they gain)
+  if (g_conv_variant != 3 && p.splitk_scratch && tiles <= 128 && kt_all >= 32) {
+    int ks = (int)std::min<long>(8, std::min<long>(512 / tiles, kt_all / 2));
+    const size_t need = (size_t)tiles * ks * BM * 64 * sizeof(float);
+    if (ks > 1 && need <= p.splitk_scratch_bytes && tiles <= kSplitKMaxTiles) {
+      d.ksplit = ks;
+      d.slabs = static_cast<float *>(p.splitk_scratch);
+      d.counters = p.splitk_counters;
+    }
+  }
   if (p.prec == kF32)
     return p.ksize == 1 ? launch_ks<float, 1>(d, wide, p.relu != 0, res, s)
                         : launch_ks<float, 3>(d, wide, p.relu != 0, res, s);

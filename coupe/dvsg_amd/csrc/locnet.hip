@@ -177,8 +177,11 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 struct Workspace {
   char *bufA, *bufB, *bufS, *r1, *r2;  // activations (element type = the run's precision)
   float *pool_part, *dpart0, *dpart1, *T, *Ft;
+  char *splitk_slabs;  // kSplitKSlabBytes of partial tiles, reused by every split-K launch
+  int *splitk_counters;  // kMaxConvLaunches x kSplitKMaxTiles tickets, zeroed once per forward
   size_t total;
 };
+constexpr int kMaxConvLaunches = 64;
 
 // Sized for float32 activations; the float16 run uses the same plan with half the bytes.
 Workspace plan(char *base, int B, int H, int W) {
@@ -202,13 +205,19 @@ Workspace plan(char *base, int B, int H, int W) {
   w.dpart1 = reinterpret_cast<float *>(take((size_t)kDenseSplits * 16 * 2048 * sizeof(float)));
   w.T = reinterpret_cast<float *>(take((size_t)B * 2 * 28 * sizeof(float)));
   w.Ft = reinterpret_cast<float *>(take((size_t)B * 50 * sizeof(float)));
+  w.splitk_slabs = take(kSplitKSlabBytes);
+  w.splitk_counters = reinterpret_cast<int *>(take((size_t)kMaxConvLaunches * kSplitKMaxTiles * sizeof(int)));
   w.total = off;
   return w;
 }
 
 int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, void *y, int Ho, int Wo,
-             const void *res, int res_H, int res_W, int res_stride, bool relu, hipStream_t s) {
+             const void *res, int res_H, int res_W, int res_stride, bool relu, const Workspace &ws, int *launch_idx,
+             hipStream_t s) {
   ConvGemm p;
+  p.splitk_scratch = ws.splitk_slabs;
+  p.splitk_scratch_bytes = kSplitKSlabBytes;
+  p.splitk_counters = ws.splitk_counters + (size_t)((*launch_idx)++ % kMaxConvLaunches) * kSplitKMaxTiles;
   p.prec = prec;
   p.x = x; p.wt = L.weights(prec); p.bias = L.bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
@@ -255,6 +264,9 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
     if (int rc_ = (call)) return rc_; \
   } while (0)
 
+  // split-K tickets of every conv launch of this pass (each launch owns its own segment)
+  DVSG_HIP(hipMemsetAsync(ws.splitk_counters, 0, (size_t)kMaxConvLaunches * kSplitKMaxTiles * sizeof(int), s));
+  int launch_idx = 0;
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
   DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.bias, ws.bufA, B, H, W, d.H1, d.W1, s));
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
@@ -269,13 +281,13 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
     const void *res = X;
     int res_h = h, res_w = w, res_stride = u.stride;
     if (u.has_shortcut) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
-      DVSG_RUN(run_conv(prec, u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, s));
+      DVSG_RUN(run_conv(prec, u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws, &launch_idx, s));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
     }
-    DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, s));
-    DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, s));
-    DVSG_RUN(run_conv(prec, u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, s));
+    DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+    DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+    DVSG_RUN(run_conv(prec, u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, ws, &launch_idx, s));
     h = ho; w = wo;
     DVSG_TAP(stage, Y, h, w, u.depth);
     ++stage;
@@ -326,8 +338,10 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
 }
 
 int conv_gemm_op(int prec, const void *x, const void *wt, const float *bias, const void *res, void *y, int B, int H,
-                 int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
+                 int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+                 size_t scratch_bytes, void *stream) {
   DVSG_REQUIRE(x && wt && bias && y, "dvsg_conv_gemm: NULL pointer");
+  DVSG_REQUIRE(!scratch || ((uintptr_t)scratch & 255) == 0, "dvsg_conv_gemm: scratch must be 256-byte aligned");
   DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && res_stride >= 1, "dvsg_conv_gemm: bad shape");
   ConvGemm p;
   p.prec = prec;
@@ -338,6 +352,13 @@ int conv_gemm_op(int prec, const void *x, const void *wt, const float *bias, con
   p.res_H = (p.Ho - 1) * res_stride + 1; p.res_W = (p.Wo - 1) * res_stride + 1;
   p.res_stride = res_stride;
   p.relu = relu;
+  const size_t cbytes = align256((size_t)kSplitKMaxTiles * sizeof(int));
+  if (scratch && scratch_bytes > cbytes) {  // [tickets | partial-tile slabs]
+    DVSG_HIP(hipMemsetAsync(scratch, 0, cbytes, as_stream(stream)));
+    p.splitk_counters = static_cast<int *>(scratch);
+    p.splitk_scratch = static_cast<char *>(scratch) + cbytes;
+    p.splitk_scratch_bytes = scratch_bytes - cbytes;
+  }
   return launch_conv_gemm(p, as_stream(stream));
 }
 
@@ -471,13 +492,17 @@ int dvsg_locnet_forward_tap_f16(const dvsg_locnet_t *net, const float *patches, 
 }
 
 int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y, int B, int H,
-                       int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
-  return conv_gemm_op(kF32, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, stream);
+                       int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+                       size_t scratch_bytes, void *stream) {
+  return conv_gemm_op(kF32, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+                      scratch_bytes, stream);
 }
 
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y, int B, int H,
-                       int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *stream) {
-  return conv_gemm_op(kF16, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, stream);
+                       int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+                       size_t scratch_bytes, void *stream) {
+  return conv_gemm_op(kF16, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+                      scratch_bytes, stream);
 }
 
 int dvsg_debug_set_option(const char *name, int value) {

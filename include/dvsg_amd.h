@@ -156,10 +156,13 @@ int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const f
  * optional ReLU as one implicit-GEMM launch.  x [B,H,W,Cin]; wt [Cout][ksize*ksize*Cin] (k order
  * kh, kw, c; BatchNorm scale already folded in); bias [Cout]; res (optional) is sampled at
  * (ho*res_stride, wo*res_stride) of a [B, (Ho-1)*res_stride+1, (Wo-1)*res_stride+1, Cout] tensor;
- * y [B,Ho,Wo,Cout] with Ho = (H-1)/stride+1.  Cin % 32 == 0, Cout % 64 == 0. */
+ * y [B,Ho,Wo,Cout] with Ho = (H-1)/stride+1.  Cin % 32 == 0, Cout % 64 == 0.
+ * scratch (optional, 256-byte aligned, >= 17 MiB to be useful): lets launches with fewer than 256
+ * output tiles (batch 1-2) split K over several workgroups per tile; the partial tiles are summed
+ * in slice order by the last workgroup to arrive, so results stay bitwise reproducible. */
 int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
-                       int res_stride, void *stream);
+                       int res_stride, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * float16 variants (BASELINE.json configs[4]: "fp16 MFMA convs").  Same arguments and the same
@@ -182,7 +185,7 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
 /* x, wt, res, y are float16 (Cin % 64 == 0); bias float32. */
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
-                       int res_stride, void *stream);
+                       int res_stride, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant").  Process-global. */
 int dvsg_debug_set_option(const char *name, int value);

@@ -111,3 +111,37 @@ def test_stabnet_evaluation_model(synthetic_weights, B, H, W):
     assert merr[~border].max() < 3e-3
     with pytest.raises(ValueError):
         sess.run(outs["s_t_pred"], {ins["patches_t"]: x[:, :-1], ins["u_t"]: u[:, :-1]})
+
+
+def test_split_k_reduction_is_exact_and_deterministic():
+    """Small-batch launches split K over several workgroups per tile (last-arriver reduction in
+    slice order): same result as the unsplit kernel up to float32 re-association, bitwise equal
+    from run to run, and correct when many tiles reduce concurrently."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    s = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(18 << 20, dtype=torch.uint8, device=dev)
+    for k, stride, cin, cout, h, w, B in [(3, 1, 256, 256, 23, 40, 1), (1, 1, 2048, 512, 23, 40, 1),
+                                          (3, 2, 256, 256, 45, 80, 1), (3, 1, 512, 512, 6, 10, 2)]:
+        x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
+        K = k * k * cin
+        wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
+        bias = torch.rand((cout,), generator=g, device=dev) - 0.5
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        res = torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5
+        outs = []
+        for sc, nb in ((0, 0), (scratch.data_ptr(), scratch.numel()), (scratch.data_ptr(), scratch.numel())):
+            y = torch.empty((B, ho, wo, cout), device=dev)
+            _lib.call("dvsg_conv_gemm_f32", x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                      y.data_ptr(), B, h, w, cin, cout, k, stride, 1, 1, sc, nb, s)
+            outs.append(y)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1], outs[2])
+        scale = float(outs[0].abs().max())
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * max(scale, 1.0)
+        w4 = wt.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2)
+        ref = torch.relu(ref.permute(0, 2, 3, 1) + res)
+        assert float((outs[1] - ref).abs().max()) <= 2e-5 * max(scale, 1.0)

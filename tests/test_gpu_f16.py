@@ -81,7 +81,7 @@ def test_conv_gemm_f16_layer(net):
         res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5).half()
         y = torch.empty((B, ho, wo, cout), device=dev, dtype=torch.float16)
         _lib.call("dvsg_conv_gemm_f16", x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(), y.data_ptr(),
-                  B, h, w, cin, cout, k, stride, 1, 1, torch.cuda.current_stream().cuda_stream)
+                  B, h, w, cin, cout, k, stride, 1, 1, 0, 0, torch.cuda.current_stream().cuda_stream)
         w4 = wt.float().reshape(cout, k, k, cin).permute(0, 3, 1, 2)
         ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2)
         ref = torch.relu(ref.permute(0, 2, 3, 1) + res.float())

@@ -55,6 +55,7 @@ def main():
                 uniq.append(s)
         shapes = uniq
     stream = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(18 << 20, dtype=torch.uint8, device=dev)   # split-K tickets + slabs (variant 3 = off)
     g = torch.Generator(device=dev).manual_seed(0)
     tot = {v: 0.0 for v in variants}
     print("%-24s %8s %5s %5s %2s %2s | " % ("layer", "M", "N", "K", "k", "s") +
@@ -76,7 +77,7 @@ def main():
         def run():
             _lib.call("dvsg_conv_gemm_" + args.precision, x.data_ptr(), wt.data_ptr(), bias.data_ptr(),
                       res.data_ptr() if has_res else 0, y.data_ptr(), B, h, w, cin, cout, k, stride, int(relu), 1,
-                      stream)
+                      scratch.data_ptr(), scratch.numel(), stream)
         for rnd in range(args.rounds + 1):
             for v in variants:
                 _lib.call("dvsg_debug_set_option", b"conv_variant", v)
