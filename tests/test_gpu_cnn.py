@@ -145,3 +145,32 @@ def test_split_k_reduction_is_exact_and_deterministic():
         ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2)
         ref = torch.relu(ref.permute(0, 2, 3, 1) + res)
         assert float((outs[1] - ref).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 17, 23), (1, 40, 300), (33, 32, 32)])
+def test_ragged_and_extreme_shapes(net, synthetic_weights, B, H, W):
+    """Tiny frames (every late feature map is 1x1), a width whose conv1 row needs a full and a
+    partial 128-pixel tile, and a batch that needs three head chunks."""
+    x = inputs.window_frames(241, B, H, W)
+    F = net.forward(x).cpu().numpy()
+    F_ref = onet.localizationNet(x, 25, synthetic_weights)
+    assert np.abs(F - F_ref).max() <= 1e-5
+    F16 = net.forward(x, precision="f16").cpu().numpy()
+    assert np.abs(F16 - F_ref).max() < 3e-3
+
+
+def test_bad_calls_are_rejected(net):
+    import torch
+    from coupe.dvsg_amd import DvsgError, _lib
+    x = torch.zeros((1, 32, 32, 21), device="cuda")
+    F = torch.zeros((1, 25, 2), device="cuda")
+    ws, nbytes = net.workspace(1, 32, 32)
+    with pytest.raises(DvsgError, match="workspace"):
+        _lib.call("dvsg_locnet_forward_f32", net.handle, x.data_ptr(), 1, 32, 32, F.data_ptr(), ws.data_ptr(), 1024, 0)
+    with pytest.raises(DvsgError, match="aligned"):
+        _lib.call("dvsg_locnet_forward_f32", net.handle, x.data_ptr(), 1, 32, 32, F.data_ptr(), ws.data_ptr() + 4,
+                  nbytes, 0)
+    with pytest.raises(DvsgError, match="bad shape"):
+        _lib.call("dvsg_locnet_forward_f32", net.handle, x.data_ptr(), 0, 32, 32, F.data_ptr(), ws.data_ptr(), nbytes, 0)
+    with pytest.raises(ValueError, match="input channels"):
+        net.forward(torch.zeros((1, 32, 32, 3), device="cuda"))
