@@ -47,8 +47,10 @@ constexpr int kConv1Cin = 21;
 constexpr int kConv1K = 7 * kConv1Cin;   // 147 taps per kernel row
 constexpr int kConv1Kpad = 148;          // rounded to the 4-k MFMA step
 constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conflict-free ds_read_b64)
-int launch_conv1(int out_prec, const float *x, const float *wt1, const float *bias, void *y, int B, int H,
-                 int W, int Ho, int Wo, hipStream_t s);
+// wt1h (float16 precision only): the same taps as [7][64][kConv1LdH] float16, rows zero-padded to 160.
+constexpr int kConv1LdH = 168;
+int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const float *bias, void *y,
+                 int B, int H, int W, int Ho, int Wo, hipStream_t s);
 
 // 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 8 == 0.
 int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,

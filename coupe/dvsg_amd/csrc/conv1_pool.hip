@@ -199,14 +199,162 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, T
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// conv1 for the float16 precision: same decomposition (one output row x 128 pixels x 64 channels
+// per workgroup, the input row segment staged once per kernel row and read in place as
+// overlapping windows), but the scaled input is stored in LDS as float16 and multiplied on
+// v_mfma_f32_32x32x16_f16.  A lane's operand is 8 consecutive taps = 16 bytes at byte offset
+// 84 pixel + 32 step + 16 h: only 4-byte aligned, so it is fetched as four ds_read_b32
+// (21 r mod 32 is a bijection: conflict-free); the weight rows are laid out with a 336-byte
+// stride (21 x 16 B) for conflict-free ds_read_b128 and arrive by LDS-DMA.  Both LDS images are
+// double-buffered: kernel row kh+1 is fetched while kh is multiplied, one barrier per row.
+// The 147 taps of a row are padded to 160 (ten 16-tap MFMA steps) with zero weights.
+// ----------------------------------------------------------------------------------------
+constexpr int C1H_STEPS = 10;
+constexpr int C1H_LD = 168;                        // halfs per weight row in LDS / global
+constexpr int C1H_WBYTES = 64 * C1H_LD * 2;        // 21504 bytes per kernel row = 21 LDS-DMA pieces
+constexpr int C1H_SEG = 5504;                      // halfs per staged input row (5481 + zero tail)
+constexpr int C1H_INPAIRS = (C1H_SEG / 2 + 255) / 256;  // 11 half2 per thread
+
+template <typename TO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1h, const float *__restrict__ bias,
+                      TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
+  static_assert(C1_TILE * C1_LDC * 4 <= 2 * C1H_WBYTES, "epilogue tile must fit in the weight stages");
+  __shared__ __attribute__((aligned(16))) char lds[2 * C1H_WBYTES + 2 * C1H_SEG * 2];
+  char *w_s = lds;
+  char *in_s = lds + 2 * C1H_WBYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int blk = blockIdx.x;
+  const int wt_i = blk % wtiles;
+  blk /= wtiles;
+  const int ho = blk % Ho;
+  const int b = blk / Ho;
+  const int wo0 = wt_i * C1_TILE;
+
+  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
+  const long row_elems = (long)W * kConv1Cin;
+  float mean_i[2 * C1H_INPAIRS];
+  int idx_i[2 * C1H_INPAIRS];
+  unsigned col_ok = 0;
+#pragma unroll
+  for (int i = 0; i < 2 * C1H_INPAIRS; ++i) {
+    const int e = 2 * (tid + 256 * (i >> 1)) + (i & 1);
+    const long ge = seg0 + e;
+    const int c = e % kConv1Cin;
+    const int g = c / (kConv1Cin / 3);
+    mean_i[i] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+    const bool ok = e < C1_SEG && ge >= 0 && ge < row_elems;
+    if (ok) col_ok |= 1u << i;
+    idx_i[i] = ok ? (int)ge : 0;
+  }
+
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  float in_reg[2 * C1H_INPAIRS];
+  bool row_ok = false;
+  auto load_stage = [&](int kh, int buf) __attribute__((always_inline)) {
+    // weights of kernel row kh: 21 pieces of 1 KiB, piece j by wave j % 4, straight into LDS
+    const char *wsrc = reinterpret_cast<const char *>(wt1h) + (size_t)kh * C1H_WBYTES;
+    for (int j = wave; j < C1H_WBYTES / 1024; j += 4)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024 + lane * 16), (lptr_t)(w_s + buf * C1H_WBYTES + j * 1024),
+                                       16, 0, 0);
+    const int hi = 2 * ho + kh - 3;
+    row_ok = hi >= 0 && hi < H;
+    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+    const float *xrow = x + ((long)b * H + hc) * row_elems;
+#pragma unroll
+    for (int i = 0; i < 2 * C1H_INPAIRS; ++i) in_reg[i] = xrow[idx_i[i]];
+  };
+  auto store_stage = [&](int buf) __attribute__((always_inline)) {
+    const unsigned ok = row_ok ? col_ok : 0u;
+    unsigned *dst = reinterpret_cast<unsigned *>(in_s + buf * C1H_SEG * 2);
+#pragma unroll
+    for (int i = 0; i < C1H_INPAIRS; ++i) {
+      const int q = tid + 256 * i;
+      // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops), then one rounding to f16
+      const float v0 = ((ok >> (2 * i)) & 1u) ? in_reg[2 * i] * 255.0f - mean_i[2 * i] : 0.f;
+      const float v1 = ((ok >> (2 * i + 1)) & 1u) ? in_reg[2 * i + 1] * 255.0f - mean_i[2 * i + 1] : 0.f;
+      typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+      half2_t hv;
+      hv[0] = (_Float16)v0;
+      hv[1] = (_Float16)v1;
+      if (q < C1H_SEG / 2) dst[q] = *reinterpret_cast<unsigned *>(&hv);
+    }
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[mi][q] = 0.f;
+
+  load_stage(0, 0);
+  store_stage(0);
+  __syncthreads();
+  for (int kh = 0; kh < 7; ++kh) {
+    const int buf = kh & 1;
+    if (kh + 1 < 7) load_stage(kh + 1, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const char *a0 = in_s + buf * C1H_SEG * 2 + 2 * (2 * kConv1Cin * (wm * 64 + r) + 8 * h);
+    const char *bp = w_s + buf * C1H_WBYTES + 2 * ((wn * 32 + r) * C1H_LD + 8 * h);
+#pragma unroll 2
+    for (int t = 0; t < C1H_STEPS; ++t) {
+      union {
+        unsigned u[4];
+        halfx8 v;
+      } fa[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const unsigned *pa = reinterpret_cast<const unsigned *>(a0 + mi * (2 * 2 * kConv1Cin * 32) + 32 * t);
+        fa[mi].u[0] = pa[0];
+        fa[mi].u[1] = pa[1];
+        fa[mi].u[2] = pa[2];
+        fa[mi].u[3] = pa[3];
+      }
+      const halfx8 fb = *reinterpret_cast<const halfx8 *>(bp + 32 * t);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0].v, fb, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1].v, fb, acc[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kh + 1 < 7) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  float *Cs = reinterpret_cast<float *>(lds);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      Cs[(wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + wn * 32 + r] = acc[mi][q];
+  __syncthreads();
+  const int col4 = tid & 15, row0 = tid >> 4;
+  const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
+  TO *yrow = y + (((size_t)b * Ho + ho) * Wo + wo0) * 64 + 4 * col4;
+#pragma unroll 4
+  for (int row = row0; row < C1_TILE; row += 16) {
+    if (wo0 + row >= Wo) break;
+    float4 v = *reinterpret_cast<const float4 *>(Cs + row * C1_LDC + 4 * col4);
+    v.x = fmaxf(v.x + b4.x, 0.f);
+    v.y = fmaxf(v.y + b4.y, 0.f);
+    v.z = fmaxf(v.z + b4.z, 0.f);
+    v.w = fmaxf(v.w + b4.w, 0.f);
+    store4(yrow + (size_t)row * 64, v);
+  }
+}
+
 int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 waves (measured equal or better), 1 = 8
 
 }  // namespace
 
 void set_conv1_variant(int v) { g_conv1_variant = v; }
 
-int launch_conv1(int out_prec, const float *x, const float *wt1, const float *bias, void *y, int B, int H,
-                 int W, int Ho, int Wo, hipStream_t s) {
+int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const float *bias, void *y,
+                 int B, int H, int W, int Ho, int Wo, hipStream_t s) {
   const int wtiles = ceil_div(Wo, C1_TILE);
   const long blocks = (long)wtiles * Ho * B;
   DVSG_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv1: grid of %ld workgroups out of range", blocks);
@@ -214,7 +362,10 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const float *bi
   ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
                  4.0 * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
   const dim3 grid((unsigned)blocks);
-  if (out_prec == kF16) {
+  if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
+    hipLaunchKernelGGL((conv1_f16_kernel<_Float16>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
+                       bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
+  } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output
     hipLaunchKernelGGL((conv1_kernel<4, _Float16>), grid, dim3(256), 0, s, x, wt1, bias,
                        static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
   } else if (g_conv1_variant == 0) {

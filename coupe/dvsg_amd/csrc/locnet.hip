@@ -152,7 +152,13 @@ int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Co
           wt[((size_t)kh * 64 + n) * kConv1Ld + kw * cin + c] =
               w->data[(((size_t)kh * 7 + kw) * cin + cs) * 64 + n] * scale[n];
       }
+  std::vector<_Float16> wth((size_t)7 * 64 * kConv1LdH, (_Float16)0.f);
+  for (int kh = 0; kh < 7; ++kh)
+    for (int n = 0; n < 64; ++n)
+      for (int k = 0; k < kConv1K; ++k)
+        wth[((size_t)kh * 64 + n) * kConv1LdH + k] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k];
   if (int rc = upload(net, wt, &L->wt)) return rc;
+  if (int rc = upload(net, wth, &L->wt16)) return rc;
   return upload(net, shift, &L->bias);
 }
 
@@ -268,7 +274,8 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
   DVSG_HIP(hipMemsetAsync(ws.splitk_counters, 0, (size_t)kMaxConvLaunches * kSplitKMaxTiles * sizeof(int), s));
   int launch_idx = 0;
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
-  DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.bias, ws.bufA, B, H, W, d.H1, d.W1, s));
+  DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.wt16, net->conv1.bias, ws.bufA, B, H, W, d.H1,
+                        d.W1, s));
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
   DVSG_RUN(launch_maxpool(prec, ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
   DVSG_TAP(1, ws.bufB, d.Hp, d.Wp, 64);
