@@ -8,6 +8,7 @@ FETCH_SIZE reads exactly half of a wide coalesced stream, so it is doubled)."""
 import csv
 import glob
 import json
+import os
 import re
 import shutil
 import sys
@@ -25,7 +26,7 @@ def short(n):
 def kclass(name):
     s = short(name)
     if s.startswith("conv_gemm"):
-        m = re.match(r"conv_gemm(?:_glds)?_kernel<(\d+), (\d+), (\d+), (\d+)", s)
+        m = re.match(r"conv_gemm_kernel<\w+, (\d+), (\d+), (\d+), (\d+)", s)   # <T, BN, WM, WN, KS, ...>
         return 1 if m and m.group(4) == "3" else 2
     for k, v in CLASSES.items():
         if s.startswith(k):
@@ -33,9 +34,14 @@ def kclass(name):
     return None
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's."""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+
 def counters(d):
-    cc = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
-    kt = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
+    cc = newest(d + "/**/*_counter_collection.csv")
+    kt = newest(d + "/**/*_kernel_trace.csv")
     dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt))}
     per = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
@@ -60,7 +66,7 @@ def write_pmc(d, path):
 
 
 def main(src, dst, tag):
-    stats = glob.glob(src + "/stats/**/*_kernel_stats.csv", recursive=True)[0]
+    stats = newest(src + "/stats/**/*_kernel_stats.csv")
     shutil.copy(stats, "%s/%s_kernel_stats.csv" % (dst, tag))
     write_pmc(src + "/pmc_sq", "%s/%s_pmc_sq.csv" % (dst, tag))
     fetch, fdisp = write_pmc(src + "/pmc_fetch", "%s/%s_pmc_fetch.csv" % (dst, tag))
