@@ -141,13 +141,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs for a one-GPU box (the real multi-GPU run uses neither): DVSG_BENCH_BACKEND=gloo
+    # stages the gather through host memory, DVSG_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0.
+    backend = os.environ.get("DVSG_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("DVSG_BENCH_SHARE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm; rendezvous comes from the launcher's MASTER_ADDR / MASTER_PORT
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    on_host = backend != "nccl"
 
     from coupe.dvsg_amd import _lib
     from coupe.dvsg_amd.networks import LocNet
@@ -162,7 +167,8 @@ def main():
     F_t = torch.empty((B, 25, 2), device=dev)
     gather_bufs = None
     if dist is not None and not args.no_gather and rank == 0:
-        gather_bufs = [[torch.empty((B, H, W, 3), device=dev) for _ in range(world)] for _ in range(2)]
+        gather_bufs = [[torch.empty((B, H, W, 3), device="cpu" if on_host else dev) for _ in range(world)]
+                       for _ in range(2)]
 
     pending = [None, None]   # in-flight gather per output buffer
 
@@ -176,7 +182,10 @@ def main():
         out = outs[slot]
         net.stabilize(patches, u_t, out, F_t, n_streams=args.streams, precision=args.precision)  # dvsg_stabilize_*
         if dist is not None and not args.no_gather:
-            pending[slot] = dist.gather(out, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
+            if on_host:   # rehearsal path: synchronous, through host memory
+                dist.gather(out.cpu(), gather_bufs[slot] if rank == 0 else None, dst=0)
+            else:
+                pending[slot] = dist.gather(out, gather_bufs[slot] if rank == 0 else None, dst=0, async_op=True)
 
     def drain():
         for slot in (0, 1):
@@ -184,10 +193,16 @@ def main():
                 pending[slot].wait()
                 pending[slot] = None
 
+    def barrier():
+        if on_host:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[dev_index])
+
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            barrier()
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -208,7 +223,7 @@ def main():
         _lib.call("dvsg_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
         prof = (ms.value, n.value, fl.value, by.value)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if on_host else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -247,7 +262,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights, H, W)
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

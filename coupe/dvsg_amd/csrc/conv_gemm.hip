@@ -343,7 +343,7 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
                  es * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * d.K +
                        (double)M * p.Cout * (p.res ? 2.0 : 1.0)));
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide.
-  const bool wide = p.Cout % 128 == 0 && (long)d.mtiles * (p.Cout / 128) >= 512;
+  const bool wide = g_conv_variant != 4 && p.Cout % 128 == 0 && (long)d.mtiles * (p.Cout / 128) >= 512;
   d.ntiles = p.Cout / (wide ? 128 : 64);
   // Split-K when the launch has too few tiles for the 512 resident workgroups (batch 1-2): slices
   // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
