@@ -52,7 +52,12 @@ struct ConvGemmDev {
   int M, K, mtiles, ntiles;
 };
 
-template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, bool SPLITK>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, bool SPLITK, int NS>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN / 2, WM * WN / 2)))
 void conv_gemm_kernel(ConvGemmDev p) {
   constexpr int NW = WM * WN;
@@ -64,11 +69,14 @@ void conv_gemm_kernel(ConvGemmDev p) {
   constexpr int BKE = ROWB / sizeof(T);     // k elements per stage: 32 (f32) / 64 (f16)
   constexpr int CHE = 16 / sizeof(T);       // elements per 16-byte chunk
   static_assert(MI >= 1 && NI >= 1 && AG >= 1 && BG >= 1, "bad tile configuration");
-  constexpr int LDS_STAGE = 2 * (BM + BN) * ROWB;
+  constexpr int LDS_STAGE = NS * (BM + BN) * ROWB;
   constexpr int LDS_EPI = BM * (BN + 4) * 4;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI];
+  constexpr int LDS_MAIN = LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI;
+  // ONE shared object (a second one makes hipcc drain vmcnt before every fragment read); the last
+  // 16 bytes carry the split-K ticket
+  __shared__ __attribute__((aligned(16))) char lds[LDS_MAIN + 16];
   char *As = lds;
-  char *Bs = lds + 2 * BM * ROWB;
+  char *Bs = lds + NS * BM * ROWB;
   const T *px = static_cast<const T *>(p.x);
   const T *pw = static_cast<const T *>(p.wt);
 
@@ -186,19 +194,45 @@ void conv_gemm_kernel(ConvGemmDev p) {
     }
   };
 
-  // __syncthreads() carries the vmcnt(0) that retires the DMA of the next stage (and orders
-  // everyone's reads of the buffer about to be refilled).
   const int KT = kt1 - kt0;
-  issue_stage(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT - 1; ++kt) {
-    issue_stage((kt + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute_stage(kt & 1);
-    __builtin_amdgcn_sched_barrier(0);
+  if (NS == 2) {
+    // __syncthreads() carries the vmcnt(0) that retires the DMA of the next stage (and orders
+    // everyone's reads of the buffer about to be refilled).
+    issue_stage(0);
     __syncthreads();
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      issue_stage((kt + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_stage(kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
+    compute_stage((KT - 1) & 1);
+  } else {
+    // Deep ring for launches with few workgroups per CU (small batch): NS-1 stages of LDS-DMA stay
+    // in flight.  A wave waits (counted vmcnt, never 0 in steady state) for ITS pieces of stage
+    // kt, the raw barrier then says every wave's pieces landed and everyone is done reading the
+    // buffer of stage kt-1, which is refilled at once with stage kt+NS-1.
+    constexpr int PER = AG + BG;  // LDS-DMA instructions per wave per stage
+    static_assert(PER * (NS - 2) < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+      if (st < KT) issue_stage(st);
+    int rd = 0, wr = NS - 1;
+    for (int kt = 0; kt < KT; ++kt) {
+      const int ahead = KT - 1 - kt < NS - 2 ? KT - 1 - kt : NS - 2;
+      if (ahead >= 2) wait_vmcnt<(NS > 3 ? 2 : 0) * PER>();
+      else if (ahead == 1) wait_vmcnt<PER>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + NS - 1 < KT) issue_stage(wr);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_stage(rd);
+      __builtin_amdgcn_sched_barrier(0);
+      rd = rd + 1 == NS ? 0 : rd + 1;
+      wr = wr + 1 == NS ? 0 : wr + 1;
+    }
   }
-  compute_stage((KT - 1) & 1);
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
   constexpr int LDC = BN + 4;
@@ -229,7 +263,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
     float *mine = const_cast<float *>(slab0) + (size_t)slice * (BM * BN);
     for (int row = row0; row < BM; row += RSTEP)
       *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
-    __shared__ int s_ticket;
+    int &s_ticket = *reinterpret_cast<int *>(lds + LDS_MAIN);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -284,11 +318,11 @@ void conv_gemm_kernel(ConvGemmDev p) {
 
 int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = by tile count, 1 = 4 waves, 2 = 8 waves
 
-template <typename T, int BN, int WM, int WN, int KS, bool SPLITK>
+template <typename T, int BN, int WM, int WN, int KS, bool SPLITK, int NS = 2>
 int launch_cfg(const ConvGemmDev &d, bool relu, int res, hipStream_t s) {
   const dim3 grid(d.mtiles * d.ntiles * (SPLITK ? d.ksplit : 1)), block(64 * WM * WN);
 #define DVSG_LAUNCH(R, Q) \
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, SPLITK>), grid, block, 0, s, d)
+  hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, SPLITK, NS>), grid, block, 0, s, d)
   if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
@@ -308,7 +342,10 @@ int launch_ks(const ConvGemmDev &d, bool wide, bool relu, int res, hipStream_t s
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
   // waves in flight.
   if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
-    return launch_cfg<T, 64, 2, 2, KS, true>(d, relu, res, s);
+    return launch_cfg<T, 64, 2, 2, KS, true, 2>(d, relu, res, s);
+  // (A 4-stage LDS-DMA ring -- the NS > 2 path of the kernel, 96 KB of LDS, one workgroup per CU --
+  // was measured for these small launches and lost 3-10 % to two 2-stage workgroups per CU, so it
+  // is not instantiated.)
   const bool four = g_conv_variant == 1 || (g_conv_variant == 0 && (long)d.mtiles * d.ntiles <= 512);
   if (four)
     return wide ? launch_cfg<T, 128, 2, 2, KS, false>(d, relu, res, s)

@@ -9,7 +9,7 @@ import inputs
 from coupe.dvsg_amd.clip import stabilize_clip
 from coupe.dvsg_amd.model import Session, StabNet
 from coupe.dvsg_amd.weights import make_synthetic_weights
-H, W = 720, 1280
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (720, 1280)
 net = StabNet(H, W).load_weights(make_synthetic_weights(0)); net.get_evaluation_model(7)
 sess = Session()
 frames = torch.from_numpy(inputs.smooth_frames(1, 4, H, W)).cuda().repeat(16, 1, 1, 1)   # 64 frames on the device
