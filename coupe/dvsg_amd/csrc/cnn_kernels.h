@@ -33,8 +33,8 @@ struct ConvGemm {
   size_t splitk_scratch_bytes = 0;
   int *splitk_counters = nullptr;
 };
-constexpr int kSplitKMaxTiles = 256;                                   // tickets one launch may use
-constexpr size_t kSplitKSlabBytes = (size_t)512 * 128 * 64 * 4;        // 16 MiB: <= 512 slices of 128x64 f32
+constexpr int kSplitKMaxTiles = 512;                                   // tickets one launch may use
+constexpr size_t kSplitKSlabBytes = (size_t)512 * 2 * 128 * 128 * 4;   // 64 MiB: 512 workgroups x 2 partial 128x128 f32 tiles (stream-K tail)
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
 void set_conv_variant(int v);   // diagnostic A/B switches (dvsg_debug_set_option)
 void set_conv1_variant(int v);

@@ -25,6 +25,17 @@
 // Epilogue: a lane of the 32x32 C/D layout owns ONE output channel, which would mean 16 dword
 // stores (and residual loads) per MFMA block per lane; instead the accumulators are transposed
 // through the idle staging LDS so every thread moves 4 consecutive channels (float4 / 4 x f16).
+//
+// Work decomposition (MODE):
+//   0  one workgroup per output tile.
+//   1  split-K: a launch with too few tiles for the chip (batch 1-2) gives each tile to `ksplit`
+//      workgroups, each running a contiguous slice of the K stages.
+//   2  stream-K tail: the tiles of the last, partly filled round of a large launch are cut into
+//      one equal share of (tile, K-stage) units per resident workgroup, so the round costs its
+//      share of the work instead of a full tile time.
+// Modes 1 and 2 reduce in the launch, last-arriver form: a contributor publishes its raw partial
+// tile, takes a ticket, and whoever draws the last ticket of a tile sums all partials in K order
+// (bitwise reproducible) and runs the epilogue.  No workgroup ever waits for another one.
 #include <algorithm>
 
 #include "cnn_device.h"
@@ -34,7 +45,8 @@ namespace dvsg {
 namespace {
 
 constexpr int BM = 128;
-constexpr int ROWB = 128;  // bytes of k per tile row and stage
+constexpr int ROWB = 128;        // bytes of k per tile row and stage
+constexpr int kResident = 512;   // workgroups of the 128-wide 8-wave configuration resident on the chip (2 per CU)
 
 // what a tap outside the image reads (conv2d_same zero padding)
 __device__ const floatx4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
@@ -43,21 +55,17 @@ struct ConvGemmDev {
   const void *x, *wt, *res;
   const float *bias;
   void *y;
-  float *slabs;    // split-K partial tiles [tile][slice][128][BN] (ksplit > 1)
-  int *counters;   // split-K arrival tickets, one per tile, zeroed before the launch
-  int ksplit;
+  float *slabs;    // partial tiles of modes 1 / 2
+  int *counters;   // arrival tickets, zeroed before the launch
+  int ksplit;      // mode 1: slices per tile
+  int tile_begin, tile_count;  // tiles [tile_begin, tile_begin + tile_count) belong to this launch
   int H, W, Cin, Ho, Wo, Cout;
   int stride, pad;
   int res_H, res_W, res_stride;
   int M, K, mtiles, ntiles;
 };
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, bool SPLITK, int NS>
+template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN / 2, WM * WN / 2)))
 void conv_gemm_kernel(ConvGemmDev p) {
   constexpr int NW = WM * WN;
@@ -69,135 +77,132 @@ void conv_gemm_kernel(ConvGemmDev p) {
   constexpr int BKE = ROWB / sizeof(T);     // k elements per stage: 32 (f32) / 64 (f16)
   constexpr int CHE = 16 / sizeof(T);       // elements per 16-byte chunk
   static_assert(MI >= 1 && NI >= 1 && AG >= 1 && BG >= 1, "bad tile configuration");
-  constexpr int LDS_STAGE = NS * (BM + BN) * ROWB;
+  constexpr int LDS_STAGE = 2 * (BM + BN) * ROWB;
   constexpr int LDS_EPI = BM * (BN + 4) * 4;
   constexpr int LDS_MAIN = LDS_STAGE > LDS_EPI ? LDS_STAGE : LDS_EPI;
   // ONE shared object (a second one makes hipcc drain vmcnt before every fragment read); the last
-  // 16 bytes carry the split-K ticket
+  // 16 bytes carry the ticket of modes 1 / 2
   __shared__ __attribute__((aligned(16))) char lds[LDS_MAIN + 16];
   char *As = lds;
-  char *Bs = lds + NS * BM * ROWB;
+  char *Bs = lds + 2 * BM * ROWB;
   const T *px = static_cast<const T *>(p.x);
   const T *pw = static_cast<const T *>(p.wt);
+  const T *pres = static_cast<const T *>(p.res);
+  T *py = static_cast<T *>(p.y);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
-
-  // split-K: the slices of one tile are adjacent logical ids (same XCD: the reducer reads its
-  // siblings' slabs out of its own L2)
-  const int logical = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * (SPLITK ? p.ksplit : 1));
-  const int tile = SPLITK ? logical / p.ksplit : logical;
-  const int slice = SPLITK ? logical - tile * p.ksplit : 0;
-  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
-  // ---- staging: wave `wave` fills row groups g = wave + NW i; lane -> row 8 g + lane / 8,
-  // LDS chunk position lane % 8, which must receive global chunk pos ^ ((row >> 1) & 7).
   const int lrow8 = lane >> 3, lpos = lane & 7;
-  long a_off[AG];       // element offset of the pixel's (kh=0, kw=0, c=chunk) tap
-  unsigned a_mask[AG];  // bit kh: input row valid, bit 4+kw: input col valid
-#pragma unroll
-  for (int i = 0; i < AG; ++i) {
-    const int row = 8 * (wave + NW * i) + lrow8;
-    const int chunk = lpos ^ ((row >> 1) & 7);
-    const int m = m0 + row;
-    const int mm = m < p.M ? m : 0;
-    const int wo = mm % p.Wo;
-    const int t = mm / p.Wo;
-    const int ho = t % p.Ho;
-    const int b = t / p.Ho;
-    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-    a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + CHE * chunk;
-    unsigned mk = 0;
-    if (m < p.M) {
-#pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        if (hi0 + q >= 0 && hi0 + q < p.H) mk |= 1u << q;
-        if (wi0 + q >= 0 && wi0 + q < p.W) mk |= 16u << q;
-      }
-    }
-    a_mask[i] = mk;
-  }
-  const T *wsrc[BG];
-#pragma unroll
-  for (int i = 0; i < BG; ++i) {
-    const int row = 8 * (wave + NW * i) + lrow8;
-    wsrc[i] = pw + (size_t)(n0 + row) * p.K + CHE * (lpos ^ ((row >> 1) & 7));
-  }
+  const int KT_all = p.K / BKE;
 
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
-  // (kh, kw, c0) of the stage being issued advance incrementally: no integer division in the loop
-  const int KT_all = p.K / BKE;
-  const int kt0 = SPLITK ? (int)((long)slice * KT_all / p.ksplit) : 0;
-  const int kt1 = SPLITK ? (int)((long)(slice + 1) * KT_all / p.ksplit) : KT_all;
-  int s_kh = 0, s_kw = 0, s_c0 = 0, s_k0 = kt0 * BKE;
-  if (SPLITK) {
-    s_c0 = s_k0;
-    if (KS > 1) {
+  typedef typename Frag<T>::type frag_t;
+
+  // One (tile, K-stage range) segment.  `n_contrib` contributors share the tile; this one is
+  // number `own` (in K order), its partial goes to slab `slab_of(own)`, the tile's ticket is
+  // `ticket_idx`.  n_contrib == 1: plain tile.
+  auto run_segment = [&](int tile, int kt0, int kt1, int n_contrib, int own, int ticket_idx,
+                         auto slab_of) __attribute__((always_inline)) {
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- staging: wave `wave` fills row groups g = wave + NW i; lane -> row 8 g + lane / 8,
+    // LDS chunk position lane % 8, which must receive global chunk pos ^ ((row >> 1) & 7).
+    long a_off[AG];       // element offset of the pixel's (kh=0, kw=0, c=chunk) tap
+    unsigned a_mask[AG];  // bit kh: input row valid, bit 4+kw: input col valid
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const int row = 8 * (wave + NW * i) + lrow8;
+      const int chunk = lpos ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      const int mm = m < p.M ? m : 0;
+      const int wo = mm % p.Wo;
+      const int t = mm / p.Wo;
+      const int ho = t % p.Ho;
+      const int b = t / p.Ho;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + CHE * chunk;
+      unsigned mk = 0;
+      if (m < p.M) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          if (hi0 + q >= 0 && hi0 + q < p.H) mk |= 1u << q;
+          if (wi0 + q >= 0 && wi0 + q < p.W) mk |= 16u << q;
+        }
+      }
+      a_mask[i] = mk;
+    }
+    const T *wsrc[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+      const int row = 8 * (wave + NW * i) + lrow8;
+      wsrc[i] = pw + (size_t)(n0 + row) * p.K + CHE * (lpos ^ ((row >> 1) & 7));
+    }
+
+    // (kh, kw, c0) of the stage being issued advance incrementally: no integer division in the loop
+    int s_kh = 0, s_kw = 0, s_k0 = kt0 * BKE, s_c0 = s_k0;
+    if (MODE != 0 && KS > 1) {
       const int tap = s_k0 / p.Cin;
       s_c0 = s_k0 - tap * p.Cin;
       s_kh = tap / KS;
       s_kw = tap - s_kh * KS;
     }
-  }
-  auto issue_stage = [&](int buf) __attribute__((always_inline)) {
-    const T *xa = px + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+    auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+      const T *xa = px + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
 #pragma unroll
-    for (int i = 0; i < AG; ++i) {
-      const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
-      const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < BG; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + s_k0),
-                                       (lptr_t)(Bs + (buf * BN + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
-    s_k0 += BKE;
-    s_c0 += BKE;
-    if (KS > 1 && s_c0 == p.Cin) {
-      s_c0 = 0;
-      if (++s_kw == KS) {
-        s_kw = 0;
-        ++s_kh;
+      for (int i = 0; i < AG; ++i) {
+        const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
+        const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
       }
-    }
-  };
+#pragma unroll
+      for (int i = 0; i < BG; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + s_k0),
+                                         (lptr_t)(Bs + (buf * BN + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
+      s_k0 += BKE;
+      s_c0 += BKE;
+      if (KS > 1 && s_c0 == p.Cin) {
+        s_c0 = 0;
+        if (++s_kw == KS) {
+          s_kw = 0;
+          ++s_kh;
+        }
+      }
+    };
 
-  floatx16 acc[MI][NI];
+    floatx16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
 
-  typedef typename Frag<T>::type frag_t;
-  const int sw = (r >> 1) & 7;  // fragment rows are 32-aligned + r, so (row >> 1) & 7 == (r >> 1) & 7
-  auto compute_stage = [&](int buf) __attribute__((always_inline)) {
-    const char *a_base = As + (buf * BM + wm * (BM / WM) + r) * ROWB;
-    const char *b_base = Bs + (buf * BN + wn * (BN / WN) + r) * ROWB;
+    const int sw = (r >> 1) & 7;  // fragment rows are 32-aligned + r, so (row >> 1) & 7 == (r >> 1) & 7
+    auto compute_stage = [&](int buf) __attribute__((always_inline)) {
+      const char *a_base = As + (buf * BM + wm * (BM / WM) + r) * ROWB;
+      const char *b_base = Bs + (buf * BN + wn * (BN / WN) + r) * ROWB;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int co = 16 * ((2 * kb + h) ^ sw);
-      frag_t a4[MI], b4[NI];
+      for (int kb = 0; kb < 4; ++kb) {
+        const int co = 16 * ((2 * kb + h) ^ sw);
+        frag_t a4[MI], b4[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a4[mi] = *reinterpret_cast<const frag_t *>(a_base + mi * 32 * ROWB + co);
+        for (int mi = 0; mi < MI; ++mi) a4[mi] = *reinterpret_cast<const frag_t *>(a_base + mi * 32 * ROWB + co);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b4[ni] = *reinterpret_cast<const frag_t *>(b_base + ni * 32 * ROWB + co);
+        for (int ni = 0; ni < NI; ++ni) b4[ni] = *reinterpret_cast<const frag_t *>(b_base + ni * 32 * ROWB + co);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Frag<T>::mma(a4[mi], b4[ni], acc[mi][ni]);
-    }
-  };
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Frag<T>::mma(a4[mi], b4[ni], acc[mi][ni]);
+      }
+    };
 
-  const int KT = kt1 - kt0;
-  if (NS == 2) {
     // __syncthreads() carries the vmcnt(0) that retires the DMA of the next stage (and orders
     // everyone's reads of the buffer about to be refilled).
+    const int KT = kt1 - kt0;
     issue_stage(0);
     __syncthreads();
     for (int kt = 0; kt < KT - 1; ++kt) {
@@ -208,121 +213,129 @@ void conv_gemm_kernel(ConvGemmDev p) {
       __syncthreads();
     }
     compute_stage((KT - 1) & 1);
-  } else {
-    // Deep ring for launches with few workgroups per CU (small batch): NS-1 stages of LDS-DMA stay
-    // in flight.  A wave waits (counted vmcnt, never 0 in steady state) for ITS pieces of stage
-    // kt, the raw barrier then says every wave's pieces landed and everyone is done reading the
-    // buffer of stage kt-1, which is refilled at once with stage kt+NS-1.
-    constexpr int PER = AG + BG;  // LDS-DMA instructions per wave per stage
-    static_assert(PER * (NS - 2) < 64, "vmcnt is a 6-bit counter");
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st)
-      if (st < KT) issue_stage(st);
-    int rd = 0, wr = NS - 1;
-    for (int kt = 0; kt < KT; ++kt) {
-      const int ahead = KT - 1 - kt < NS - 2 ? KT - 1 - kt : NS - 2;
-      if (ahead >= 2) wait_vmcnt<(NS > 3 ? 2 : 0) * PER>();
-      else if (ahead == 1) wait_vmcnt<PER>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + NS - 1 < KT) issue_stage(wr);
-      __builtin_amdgcn_sched_barrier(0);
-      compute_stage(rd);
-      __builtin_amdgcn_sched_barrier(0);
-      rd = rd + 1 == NS ? 0 : rd + 1;
-      wr = wr + 1 == NS ? 0 : wr + 1;
-    }
-  }
 
-  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
-  constexpr int LDC = BN + 4;
-  float *Cs = reinterpret_cast<float *>(lds);
-  __syncthreads();
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-        Cs[(wm * (BM / WM) + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * LDC + wn * (BN / WN) + ni * 32 + r] =
-            acc[mi][ni][q];
-  __syncthreads();
-  constexpr int C4 = BN / 4;       // 4-channel groups per tile row
-  constexpr int RSTEP = NT / C4;   // tile rows covered per pass
-  const int col4 = tid % C4, row0 = tid / C4;
-  const int n = n0 + 4 * col4;
-  const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
-  const T *pres = static_cast<const T *>(p.res);
-  T *py = static_cast<T *>(p.y);
-  const float *slab0 = nullptr;
-  if (SPLITK) {
-    // In-launch split-K reduction, last-arriver form (no block ever waits for another one):
-    // every slice publishes its raw partial tile, takes a ticket, and the slice that draws the
-    // last ticket sums all partials IN SLICE ORDER (bitwise reproducible) and runs the epilogue.
-    slab0 = p.slabs + (size_t)tile * p.ksplit * (BM * BN);
-    float *mine = const_cast<float *>(slab0) + (size_t)slice * (BM * BN);
-    for (int row = row0; row < BM; row += RSTEP)
-      *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
-    int &s_ticket = *reinterpret_cast<int *>(lds + LDS_MAIN);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
+    constexpr int LDC = BN + 4;
+    float *Cs = reinterpret_cast<float *>(lds);
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          Cs[(wm * (BM / WM) + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * LDC + wn * (BN / WN) + ni * 32 + r] =
+              acc[mi][ni][q];
+    __syncthreads();
+    constexpr int C4 = BN / 4;       // 4-channel groups per tile row
+    constexpr int RSTEP = NT / C4;   // tile rows covered per pass
+    const int col4 = tid % C4, row0 = tid / C4;
+    const int n = n0 + 4 * col4;
+    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+    if (MODE != 0 && n_contrib > 1) {
+      float *mine = slab_of(own);
+      for (int row = row0; row < BM; row += RSTEP)
+        *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
+      int &s_ticket = *reinterpret_cast<int *>(lds + LDS_MAIN);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      s_ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(p.counters + ticket_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (s_ticket != n_contrib - 1) return;  // someone else will finish this tile
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (s_ticket != p.ksplit - 1) return;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-  }
 #pragma unroll 4
-  for (int row = row0; row < BM; row += RSTEP) {
-    const int m = m0 + row;
-    if (m >= p.M) break;
-    float4 v;
-    if (SPLITK) {
-      v = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int sl = 0; sl < p.ksplit; ++sl) {
-        const float4 t = sl == slice ? *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4)
-                                     : *reinterpret_cast<const float4 *>(slab0 + ((size_t)sl * BM + row) * BN + 4 * col4);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    for (int row = row0; row < BM; row += RSTEP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      float4 v;
+      if (MODE != 0 && n_contrib > 1) {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < n_contrib; ++j) {
+          const float4 t = j == own ? *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4)
+                                    : *reinterpret_cast<const float4 *>(slab_of(j) + row * BN + 4 * col4);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+      } else {
+        v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
       }
-    } else {
-      v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
-    }
-    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-    if (RES != 0) {
-      size_t roff;
-      if (RES == 1) {
-        roff = (size_t)m * p.Cout + n;
-      } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
-        const int wo = m % p.Wo;
-        const int t = m / p.Wo;
-        const int ho = t % p.Ho;
-        const int b = t / p.Ho;
-        roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (RES != 0) {
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        const float4 rv = load4(pres + roff);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
-      const float4 rv = load4(pres + roff);
-      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      if (RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      store4(py + (size_t)m * p.Cout + n, v);
     }
-    if (RELU) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  };
+
+  if (MODE == 0) {
+    const int tile = p.tile_begin + xcd_remap(blockIdx.x, p.tile_count);
+    run_segment(tile, 0, KT_all, 1, 0, 0, [&](int) -> float * { return nullptr; });
+  } else if (MODE == 1) {
+    // the slices of one tile are adjacent logical ids (same XCD: the reducer reads its siblings'
+    // slabs out of its own L2)
+    const int logical = xcd_remap(blockIdx.x, p.tile_count * p.ksplit);
+    const int tile = logical / p.ksplit, slice = logical - tile * p.ksplit;
+    const int kt0 = (int)((long)slice * KT_all / p.ksplit), kt1 = (int)((long)(slice + 1) * KT_all / p.ksplit);
+    run_segment(p.tile_begin + tile, kt0, kt1, p.ksplit, slice, tile,
+                [&](int j) -> float * { return p.slabs + ((size_t)tile * p.ksplit + j) * (BM * BN); });
+  } else {
+    // stream-K tail: workgroup w of G owns units [w U / G, (w + 1) U / G) of the U = tile_count x KT
+    // (tile, stage) units, i.e. the end of one tile and / or the beginning of the next.
+    const long G = gridDim.x;
+    const long U = (long)p.tile_count * KT_all;
+    const int w = xcd_remap(blockIdx.x, (int)G);
+    auto first_unit = [&](long wg) -> long { return wg * U / G; };
+    auto owner = [&](long u) -> int { return (int)(((u + 1) * G - 1) / U); };  // largest wg with first_unit(wg) <= u
+    long u = first_unit(w);
+    const long u_end = first_unit(w + 1);
+    while (u < u_end) {
+      const int t_local = (int)(u / KT_all);
+      const int kt0 = (int)(u - (long)t_local * KT_all);
+      const long kt_to = kt0 + (u_end - u);
+      const int kt1 = kt_to < KT_all ? (int)kt_to : KT_all;
+      const int w_first = owner((long)t_local * KT_all), w_last = owner((long)t_local * KT_all + KT_all - 1);
+      // contributor wg keeps this tile's partial in its slot 0 if the tile is where its range begins, else slot 1
+      auto slab_of = [&](int j) -> float * {
+        const long wg = w_first + j;
+        const int slot = first_unit(wg) / KT_all == t_local ? 0 : 1;
+        return p.slabs + ((size_t)wg * 2 + slot) * (BM * BN);
+      };
+      run_segment(p.tile_begin + t_local, kt0, kt1, w_last - w_first + 1, w - w_first, t_local, slab_of);
+      u += kt1 - kt0;
+      __syncthreads();  // the next segment restages the LDS this one's epilogue was reading
     }
-    store4(py + (size_t)m * p.Cout + n, v);
   }
 }
 
-int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = by tile count, 1 = 4 waves, 2 = 8 waves
+int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = auto, 1 = 4 waves, 2 = 8 waves,
+                         // 3 = no split-K, 4 = 64-wide tiles only, 6 = no stream-K tail
 
-template <typename T, int BN, int WM, int WN, int KS, bool SPLITK, int NS = 2>
-int launch_cfg(const ConvGemmDev &d, bool relu, int res, hipStream_t s) {
-  const dim3 grid(d.mtiles * d.ntiles * (SPLITK ? d.ksplit : 1)), block(64 * WM * WN);
-#define DVSG_LAUNCH(R, Q) \
-  hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, SPLITK, NS>), grid, block, 0, s, d)
+template <typename T, int BN, int WM, int WN, int KS, int MODE>
+int launch_cfg(const ConvGemmDev &d, int blocks, bool relu, int res, hipStream_t s) {
+  const dim3 grid(blocks), block(64 * WM * WN);
+#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, MODE>), grid, block, 0, s, d)
   if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
@@ -337,20 +350,30 @@ int launch_cfg(const ConvGemmDev &d, bool relu, int res, hipStream_t s) {
 }
 
 template <typename T, int KS>
-int launch_ks(const ConvGemmDev &d, bool wide, bool relu, int res, hipStream_t s) {
+int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hipStream_t s) {
+  const int tiles = d.mtiles * d.ntiles;
+  d.tile_begin = 0;
+  d.tile_count = tiles;
+  if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
+    return launch_cfg<T, 64, 2, 2, KS, 1>(d, tiles * d.ksplit, relu, res, s);
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
-  // waves in flight.
-  if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
-    return launch_cfg<T, 64, 2, 2, KS, true, 2>(d, relu, res, s);
-  // (A 4-stage LDS-DMA ring -- the NS > 2 path of the kernel, 96 KB of LDS, one workgroup per CU --
-  // was measured for these small launches and lost 3-10 % to two 2-stage workgroups per CU, so it
-  // is not instantiated.)
-  const bool four = g_conv_variant == 1 || (g_conv_variant == 0 && (long)d.mtiles * d.ntiles <= 512);
+  // waves in flight.  (A 4-stage LDS-DMA ring, 96 KB of LDS and one workgroup per CU, was measured
+  // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.)
+  const bool four = g_conv_variant == 1 || ((g_conv_variant == 0 || g_conv_variant == 6) && tiles <= 512);
   if (four)
-    return wide ? launch_cfg<T, 128, 2, 2, KS, false>(d, relu, res, s)
-                : launch_cfg<T, 64, 2, 2, KS, false>(d, relu, res, s);
-  return wide ? launch_cfg<T, 128, 2, 4, KS, false>(d, relu, res, s) : launch_cfg<T, 64, 4, 2, KS, false>(d, relu, res, s);
+    return wide ? launch_cfg<T, 128, 2, 2, KS, 0>(d, tiles, relu, res, s)
+                : launch_cfg<T, 64, 2, 2, KS, 0>(d, tiles, relu, res, s);
+  if (!wide) return launch_cfg<T, 64, 4, 2, KS, 0>(d, tiles, relu, res, s);
+  if (streamk_tail > 0) {
+    // full rounds as plain tiles, then the partly filled last round as equal unit shares
+    d.tile_count = tiles - streamk_tail;
+    if (int rc = launch_cfg<T, 128, 2, 4, KS, 0>(d, d.tile_count, relu, res, s)) return rc;
+    d.tile_begin = tiles - streamk_tail;
+    d.tile_count = streamk_tail;
+    return launch_cfg<T, 128, 2, 4, KS, 2>(d, kResident, relu, res, s);
+  }
+  return launch_cfg<T, 128, 2, 4, KS, 0>(d, tiles, relu, res, s);
 }
 
 }  // namespace
@@ -382,29 +405,37 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide.
   const bool wide = g_conv_variant != 4 && p.Cout % 128 == 0 && (long)d.mtiles * (p.Cout / 128) >= 512;
   d.ntiles = p.Cout / (wide ? 128 : 64);
-  // Split-K when the launch has too few tiles for the 512 resident workgroups (batch 1-2): slices
-  // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
   d.ksplit = 1;
-  d.slabs = nullptr;
-  d.counters = nullptr;
+  d.slabs = static_cast<float *>(p.splitk_scratch);
+  d.counters = p.splitk_counters;
   const long tiles = (long)d.mtiles * d.ntiles;
   const int kt_all = d.K / bke;
+  // Split-K when the launch has too few tiles for the 512 resident workgroups (batch 1-2): slices
+  // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
   // (measured at batch 1, 720p: pays for <= 128 tiles and K rows of >= 4 KiB, i.e. the 3x3 convs of
   // blocks 3-4 and block 4's 1x1 convs; shorter K loops lose more to the reduction than they gain)
   if (g_conv_variant != 3 && p.splitk_scratch && tiles <= 128 && kt_all >= 32) {
-    int ks = (int)std::min<long>(8, std::min<long>(512 / tiles, kt_all / 2));
+    const int ks = (int)std::min<long>(8, std::min<long>(kResident / tiles, kt_all / 2));
     const size_t need = (size_t)tiles * ks * BM * 64 * sizeof(float);
-    if (ks > 1 && need <= p.splitk_scratch_bytes && tiles <= kSplitKMaxTiles) {
-      d.ksplit = ks;
-      d.slabs = static_cast<float *>(p.splitk_scratch);
-      d.counters = p.splitk_counters;
-    }
+    if (ks > 1 && need <= p.splitk_scratch_bytes && tiles <= kSplitKMaxTiles) d.ksplit = ks;
+  }
+  // Stream-K tail for the big 128-wide launches: only when the last round is clearly under-filled,
+  // every workgroup's share is at least two K stages, and K rows are >= 4.5 KiB (the 3x3 convs of
+  // blocks 2-3 at batch 16, 720p: -5.5 % / -6 % per launch).  Measured on the same layers' 1x1
+  // neighbours (K rows of 2-4 KiB) the partial tiles, 64 KiB each way, cost more than the tail saves.
+  int streamk_tail = 0;
+  if (g_conv_variant == 0 && wide && p.splitk_scratch && tiles > kResident) {
+    const int r = (int)(tiles % kResident);
+    const size_t need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
+    if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 36 && (long)r * kt_all >= 2L * kResident && r <= kSplitKMaxTiles &&
+        need <= p.splitk_scratch_bytes)
+      streamk_tail = r;
   }
   if (p.prec == kF32)
-    return p.ksize == 1 ? launch_ks<float, 1>(d, wide, p.relu != 0, res, s)
-                        : launch_ks<float, 3>(d, wide, p.relu != 0, res, s);
-  return p.ksize == 1 ? launch_ks<_Float16, 1>(d, wide, p.relu != 0, res, s)
-                      : launch_ks<_Float16, 3>(d, wide, p.relu != 0, res, s);
+    return p.ksize == 1 ? launch_ks<float, 1>(d, wide, streamk_tail, p.relu != 0, res, s)
+                        : launch_ks<float, 3>(d, wide, streamk_tail, p.relu != 0, res, s);
+  return p.ksize == 1 ? launch_ks<_Float16, 1>(d, wide, streamk_tail, p.relu != 0, res, s)
+                      : launch_ks<_Float16, 3>(d, wide, streamk_tail, p.relu != 0, res, s);
 }
 
 }  // namespace dvsg

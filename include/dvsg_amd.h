@@ -157,9 +157,11 @@ int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const f
  * kh, kw, c; BatchNorm scale already folded in); bias [Cout]; res (optional) is sampled at
  * (ho*res_stride, wo*res_stride) of a [B, (Ho-1)*res_stride+1, (Wo-1)*res_stride+1, Cout] tensor;
  * y [B,Ho,Wo,Cout] with Ho = (H-1)/stride+1.  Cin % 32 == 0, Cout % 64 == 0.
- * scratch (optional, 256-byte aligned, >= 17 MiB to be useful): lets launches with fewer than 256
- * output tiles (batch 1-2) split K over several workgroups per tile; the partial tiles are summed
- * in slice order by the last workgroup to arrive, so results stay bitwise reproducible. */
+ * scratch (optional, 256-byte aligned; 17 MiB serves split-K, 65 MiB also the stream-K tail): lets
+ * launches with few output tiles (batch 1-2) split K over several workgroups per tile, and lets
+ * large launches cut the partly filled last round of tiles into equal (tile, K-stage) shares; the
+ * partial tiles are summed in K order by the last workgroup to arrive, so results stay bitwise
+ * reproducible from run to run. */
 int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                        int res_stride, void *scratch, size_t scratch_bytes, void *stream);

@@ -114,17 +114,20 @@ def test_stabnet_evaluation_model(synthetic_weights, B, H, W):
 
 
 def test_split_k_reduction_is_exact_and_deterministic():
-    """Small-batch launches split K over several workgroups per tile (last-arriver reduction in
-    slice order): same result as the unsplit kernel up to float32 re-association, bitwise equal
-    from run to run, and correct when many tiles reduce concurrently."""
+    """Small-batch launches split K over several workgroups per tile, large launches cut their
+    partly filled last round of tiles into equal (tile, K-stage) shares (stream-K tail); both
+    reduce last-arriver in K order: same result as the plain kernel up to float32 re-association,
+    bitwise equal from run to run, and correct when many tiles reduce concurrently."""
     import torch
     from coupe.dvsg_amd import _lib
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
     s = torch.cuda.current_stream().cuda_stream
-    scratch = torch.empty(18 << 20, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
     for k, stride, cin, cout, h, w, B in [(3, 1, 256, 256, 23, 40, 1), (1, 1, 2048, 512, 23, 40, 1),
-                                          (3, 2, 256, 256, 45, 80, 1), (3, 1, 512, 512, 6, 10, 2)]:
+                                          (3, 2, 256, 256, 45, 80, 1), (3, 1, 512, 512, 6, 10, 2),
+                                          # stream-K tails: 573 tiles (ragged last one) and 900 tiles
+                                          (3, 1, 128, 128, 91, 161, 5), (1, 1, 512, 256, 90, 160, 4)]:
         x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
         K = k * k * cin
         wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)

@@ -55,7 +55,7 @@ def main():
                 uniq.append(s)
         shapes = uniq
     stream = torch.cuda.current_stream().cuda_stream
-    scratch = torch.empty(18 << 20, dtype=torch.uint8, device=dev)   # split-K tickets + slabs (variant 3 = off)
+    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)   # split-K / stream-K tickets + slabs (variants 3 / 6 = off)
     g = torch.Generator(device=dev).manual_seed(0)
     tot = {v: 0.0 for v in variants}
     print("%-24s %8s %5s %5s %2s %2s | " % ("layer", "M", "N", "K", "k", "s") +
