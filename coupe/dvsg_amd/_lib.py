@@ -42,6 +42,11 @@ SIGNATURES = {
     "dvsg_stabilize_f16": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
+    "dvsg_frames_u8_to_f32": [_vp, ctypes.c_size_t, _i, _vp, _vp],
+    "dvsg_frames_resize_u8_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
+    "dvsg_window_gather_f32": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+    "dvsg_frames_f32_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    "dvsg_frames_f64_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_debug_set_option": [ctypes.c_char_p, _i],
     "dvsg_prof_begin": [_i],
     "dvsg_prof_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double),

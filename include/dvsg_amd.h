@@ -189,6 +189,38 @@ int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const v
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                        int res_stride, void *scratch, size_t scratch_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Data formats either side of the path (the reference's eval.py driver, which keeps frames in
+ * host NumPy arrays; here they stay in HBM).  channel_flip != 0 reverses the three channels of
+ * every pixel (cv2's BGR <-> RGB, eval.py:79,113).
+ * ------------------------------------------------------------------------------------- */
+/* eval.py:80 `frame / 255.` (float64) as TF receives it (float32): dst = (float)((double)src / 255.0).
+ * src [n_pixels*3] uint8, dst [n_pixels*3] float32 (16-byte aligned). */
+int dvsg_frames_u8_to_f32(const uint8_t *src, size_t n_pixels, int channel_flip, float *dst, void *stream);
+/* eval.py:80 with a size change: cv2.resize(frame / 255., (dst_W, dst_H)), default INTER_LINEAR,
+ * on float64, result as float32.  src [n,src_H,src_W,3] uint8 -> dst [n,dst_H,dst_W,3] float32.
+ * OpenCV is neither in the reference tree nor in this image: restated from its published
+ * algorithm, parity unpinned.  u8_dst (optional) [n,dst_H,u8_W,3] receives np.uint8(resized * 255.)
+ * -- rendered from the float64 value, as eval.py:112 does for the unstable half of its output
+ * video -- in columns [u8_x0, u8_x0 + dst_W), in the channel order of src. */
+int dvsg_frames_resize_u8_f32(const uint8_t *src, int n, int src_H, int src_W, int channel_flip, float *dst,
+                              int dst_H, int dst_W, uint8_t *u8_dst, int u8_W, int u8_x0, void *stream);
+/* eval.py:103-104 `np.concatenate(total_frames[sample_idx], axis=2)` for B windows at once:
+ * patches[b, y, x, 3 s + c] = pool[idx[b*S + s], y, x, c].  pool [n_pool,H,W,3] float32, idx [B*S]
+ * int32 ON THE DEVICE, patches [B,H,W,3S] float32 (16-byte aligned).  An index outside
+ * [0, n_pool) reads as a frame of zeros. */
+int dvsg_window_gather_f32(const float *pool, int n_pool, int H, int W, const int32_t *idx, int B, int S,
+                           float *patches, void *stream);
+/* eval.py:112 `np.uint8(x * 255.)`: float64 product, truncation toward zero (values outside
+ * [0, 256) saturate; NumPy leaves them undefined).  src [n,H,W,3] float32 is written into columns
+ * [dst_x0, dst_x0 + W) of dst [n,H,dst_W,3] uint8 -- dst_W = 2 W and dst_x0 = 0 / W give the
+ * reference's side-by-side layout, dst_W = W and dst_x0 = 0 a plain frame. */
+int dvsg_frames_f32_to_u8(const float *src, int n, int H, int W, int channel_flip, uint8_t *dst, int dst_W,
+                          int dst_x0, void *stream);
+/* same for frames the caller holds as float64 (the dtype of eval.py's history list) */
+int dvsg_frames_f64_to_u8(const double *src, int n, int H, int W, int channel_flip, uint8_t *dst, int dst_W,
+                          int dst_x0, void *stream);
+
 /* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant").  Process-global. */
 int dvsg_debug_set_option(const char *name, int value);
 

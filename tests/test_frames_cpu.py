@@ -1,0 +1,59 @@
+"""Host logic and oracle known-answer tests for the frame formats either side of the path
+(eval.py:76-124): the clip loop's index table, uint8 conversion and the cv2.resize restatement.
+cv2 is not installed (parity unpinned, see oracle/frames.py): the resize KATs below follow from
+OpenCV's published INTER_LINEAR definition, not from running it."""
+import numpy as np
+import pytest
+
+from coupe.dvsg_amd.clip import SKIP_LENGTH, window_index_table
+from oracle import frames as oframes
+
+
+@pytest.mark.parametrize("n,skip", [(1, SKIP_LENGTH), (2, SKIP_LENGTH), (33, SKIP_LENGTH), (70, SKIP_LENGTH),
+                                    (6, (0, 2, 3)), (4, (0,))])
+def test_index_table_replays_the_reference_list_manipulation(n, skip):
+    trace = oframes.window_index_trace(n, skip)
+    want = np.array([[i if kind == 'u' else n + i for kind, i in row] for row in trace])
+    got = window_index_table(n, skip)
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+    # a step never reads a stabilised frame that has not been produced yet
+    assert np.all(got[:, :-1] < n + np.arange(n)[:, None]) and np.array_equal(got[:, -1], np.arange(n))
+
+
+def test_index_table_rejects_offsets_the_reference_loop_cannot_run():
+    for bad in [(1, 2, 3), (0, 3, 3), (0, 5, 2), ()]:
+        with pytest.raises(ValueError):
+            window_index_table(4, bad)
+
+
+def test_uint8_round_trip_through_the_float_history():
+    """eval.py:80 then :112 on an untouched frame gives the frame back, also after the float32
+    cast TF applies to what it is fed."""
+    u = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(oframes.to_uint8(u / 255.), u)
+    assert np.array_equal(oframes.to_uint8(np.float32(u / 255.)), u)
+    assert np.array_equal(oframes.to_uint8(np.array([0.999999, 0.5, 1e-9])), [254, 127, 0])   # truncation
+
+
+def test_resize_known_answers():
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 1, (12, 20, 3))
+    assert np.array_equal(oframes.resize_linear(img, 20, 12), img)                   # same size: a copy
+    const = np.full((9, 7, 3), 0.37)
+    assert np.abs(oframes.resize_linear(const, 13, 5) - 0.37).max() < 1e-7          # float32 weights sum to 1
+    half = oframes.resize_linear(img, 10, 6)                                         # exact 2x: 2x2 box mean
+    box = 0.25 * (img[0::2, 0::2] + img[1::2, 0::2] + img[0::2, 1::2] + img[1::2, 1::2])
+    assert np.abs(half - box).max() < 1e-15
+    up = oframes.resize_linear(img, 40, 24)                                          # 2x up: edges clamp
+    assert np.array_equal(up[0, 0], img[0, 0]) and np.array_equal(up[-1, -1], img[-1, -1])
+    assert np.allclose(up[0, 1], 0.75 * img[0, 0] + 0.25 * img[0, 1], atol=1e-7)    # centre (1+.5)/2-.5 = .25
+    ramp = np.tile(np.arange(16.0)[None, :, None], (4, 1, 3))                        # linear data stays linear
+    r = oframes.resize_linear(ramp, 8, 4)
+    assert np.allclose(r[0, :, 0], np.arange(8) * 2 + 0.5, atol=1e-6)
+
+
+def test_read_frame_flips_bgr_and_scales():
+    bgr = np.zeros((4, 6, 3), np.uint8)
+    bgr[..., 0], bgr[..., 2] = 255, 51
+    f = oframes.read_frame(bgr, 6, 4)
+    assert f.dtype == np.float64 and np.array_equal(f[0, 0], [0.2, 0.0, 1.0])
