@@ -46,6 +46,7 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int ROWB = 128;        // bytes of k per tile row and stage
+static_assert(kSplitKMaxTiles >= 512, "a stream-K launch has up to 511 tiles, one ticket each");
 constexpr int kResident = 512;   // workgroups of the 128-wide 8-wave configuration resident on the chip (2 per CU)
 
 // what a tap outside the image reads (conv2d_same zero padding)
@@ -356,6 +357,17 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
   d.tile_count = tiles;
   if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
     return launch_cfg<T, 64, 2, 2, KS, 1>(d, tiles * d.ksplit, relu, res, s);
+  if (wide && streamk_tail > 0) {
+    // full rounds as plain tiles, then the rest (the partly filled last round, or a launch that is
+    // less than one round) as equal shares of (tile, K-stage) units
+    if (tiles > streamk_tail) {
+      d.tile_count = tiles - streamk_tail;
+      if (int rc = launch_cfg<T, 128, 2, 4, KS, 0>(d, d.tile_count, relu, res, s)) return rc;
+    }
+    d.tile_begin = tiles - streamk_tail;
+    d.tile_count = streamk_tail;
+    return launch_cfg<T, 128, 2, 4, KS, 2>(d, kResident, relu, res, s);
+  }
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
   // waves in flight.  (A 4-stage LDS-DMA ring, 96 KB of LDS and one workgroup per CU, was measured
@@ -365,14 +377,6 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
     return wide ? launch_cfg<T, 128, 2, 2, KS, 0>(d, tiles, relu, res, s)
                 : launch_cfg<T, 64, 2, 2, KS, 0>(d, tiles, relu, res, s);
   if (!wide) return launch_cfg<T, 64, 4, 2, KS, 0>(d, tiles, relu, res, s);
-  if (streamk_tail > 0) {
-    // full rounds as plain tiles, then the partly filled last round as equal unit shares
-    d.tile_count = tiles - streamk_tail;
-    if (int rc = launch_cfg<T, 128, 2, 4, KS, 0>(d, d.tile_count, relu, res, s)) return rc;
-    d.tile_begin = tiles - streamk_tail;
-    d.tile_count = streamk_tail;
-    return launch_cfg<T, 128, 2, 4, KS, 2>(d, kResident, relu, res, s);
-  }
   return launch_cfg<T, 128, 2, 4, KS, 0>(d, tiles, relu, res, s);
 }
 
@@ -402,19 +406,25 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   ProfScope prof(p.ksize == 3 ? kClsConv3x3 : kClsConv1x1, s, 2.0 * (double)M * p.Cout * d.K,
                  es * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * d.K +
                        (double)M * p.Cout * (p.res ? 2.0 : 1.0)));
-  // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide.
-  const bool wide = g_conv_variant != 4 && p.Cout % 128 == 0 && (long)d.mtiles * (p.Cout / 128) >= 512;
+  // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide -- except that a
+  // launch of 256..511 wide tiles with a long K loop runs wide as ONE stream-K round (block 4 at
+  // batch 16, 720p: 460 wide tiles, or 920 narrow ones = 1.8 rounds, both 90 % full otherwise).
+  const long tiles128 = p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
+  const int kt_all = d.K / bke;
+  const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
+  const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes;
+  const bool streamk_all = streamk_ok && tiles128 >= kResident / 4 && tiles128 < kResident && kt_all >= 32;
+  const bool wide = g_conv_variant != 4 && (tiles128 >= kResident || streamk_all);
   d.ntiles = p.Cout / (wide ? 128 : 64);
   d.ksplit = 1;
   d.slabs = static_cast<float *>(p.splitk_scratch);
   d.counters = p.splitk_counters;
   const long tiles = (long)d.mtiles * d.ntiles;
-  const int kt_all = d.K / bke;
   // Split-K when the launch has too few tiles for the 512 resident workgroups (batch 1-2): slices
   // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
   // (measured at batch 1, 720p: pays for <= 128 tiles and K rows of >= 4 KiB, i.e. the 3x3 convs of
   // blocks 3-4 and block 4's 1x1 convs; shorter K loops lose more to the reduction than they gain)
-  if (g_conv_variant != 3 && p.splitk_scratch && tiles <= 128 && kt_all >= 32) {
+  if (g_conv_variant != 3 && p.splitk_scratch && !wide && tiles <= 128 && kt_all >= 32) {
     const int ks = (int)std::min<long>(8, std::min<long>(kResident / tiles, kt_all / 2));
     const size_t need = (size_t)tiles * ks * BM * 64 * sizeof(float);
     if (ks > 1 && need <= p.splitk_scratch_bytes && tiles <= kSplitKMaxTiles) d.ksplit = ks;
@@ -423,13 +433,14 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // every workgroup's share is at least two K stages, and K rows are >= 4.5 KiB (the 3x3 convs of
   // blocks 2-3 at batch 16, 720p: -5.5 % / -6 % per launch).  Measured on the same layers' 1x1
   // neighbours (K rows of 2-4 KiB) the partial tiles, 64 KiB each way, cost more than the tail saves.
+  // (Measured and rejected: the same tail treatment for the 64-wide tiles of block 1 -- K rows of
+  // 2.3 KiB, shares of ~9 stages -- lost 2-6 % per launch.)
   int streamk_tail = 0;
-  if (g_conv_variant == 0 && wide && p.splitk_scratch && tiles > kResident) {
+  if (streamk_all) {
+    streamk_tail = (int)tiles;
+  } else if (streamk_ok && wide && d.ksplit == 1 && tiles > kResident) {
     const int r = (int)(tiles % kResident);
-    const size_t need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
-    if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 36 && (long)r * kt_all >= 2L * kResident && r <= kSplitKMaxTiles &&
-        need <= p.splitk_scratch_bytes)
-      streamk_tail = r;
+    if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 36 && (long)r * kt_all >= 2L * kResident) streamk_tail = r;
   }
   if (p.prec == kF32)
     return p.ksize == 1 ? launch_ks<float, 1>(d, wide, streamk_tail, p.relu != 0, res, s)

@@ -127,7 +127,11 @@ def test_split_k_reduction_is_exact_and_deterministic():
     for k, stride, cin, cout, h, w, B in [(3, 1, 256, 256, 23, 40, 1), (1, 1, 2048, 512, 23, 40, 1),
                                           (3, 2, 256, 256, 45, 80, 1), (3, 1, 512, 512, 6, 10, 2),
                                           # stream-K tails: 573 tiles (ragged last one) and 900 tiles
-                                          (3, 1, 128, 128, 91, 161, 5), (1, 1, 512, 256, 90, 160, 4)]:
+                                          (3, 1, 128, 128, 91, 161, 5), (1, 1, 512, 256, 90, 160, 4),
+                                          # whole launch as one stream-K round: 450 and 460 wide tiles
+                                          (3, 1, 256, 256, 45, 80, 8), (1, 1, 1024, 512, 23, 40, 16),
+                                          # 64-wide tiles, several rounds: plain path
+                                          (3, 1, 64, 64, 90, 160, 6)]:
         x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
         K = k * k * cin
         wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
