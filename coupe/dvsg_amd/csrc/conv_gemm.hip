@@ -302,11 +302,17 @@ void conv_gemm_kernel(ConvGemmDev p) {
     run_segment(p.tile_begin + tile, kt0, kt1, p.ksplit, slice, tile,
                 [&](int j) -> float * { return p.slabs + ((size_t)tile * p.ksplit + j) * (BM * BN); });
   } else {
-    // stream-K tail: workgroup w of G owns units [w U / G, (w + 1) U / G) of the U = tile_count x KT
-    // (tile, stage) units, i.e. the end of one tile and / or the beginning of the next.
-    const long G = gridDim.x;
+    // Blocks [0, tile_begin) run the plain tiles of the full rounds; the G blocks after them share
+    // the rest: workgroup w of G owns units [w U / G, (w + 1) U / G) of the U = tile_count x KT
+    // (tile, stage) units, i.e. the end of one tile and / or the beginning of the next.  One launch:
+    // the shares are dealt as the last full round drains, with no idle gap between two kernels.
+    if ((int)blockIdx.x < p.tile_begin) {
+      run_segment(xcd_remap(blockIdx.x, p.tile_begin), 0, KT_all, 1, 0, 0, [&](int) -> float * { return nullptr; });
+      return;
+    }
+    const long G = (long)gridDim.x - p.tile_begin;
     const long U = (long)p.tile_count * KT_all;
-    const int w = xcd_remap(blockIdx.x, (int)G);
+    const int w = xcd_remap((int)blockIdx.x - p.tile_begin, (int)G);
     auto first_unit = [&](long wg) -> long { return wg * U / G; };
     auto owner = [&](long u) -> int { return (int)(((u + 1) * G - 1) / U); };  // largest wg with first_unit(wg) <= u
     long u = first_unit(w);
@@ -360,13 +366,9 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
   if (wide && streamk_tail > 0) {
     // full rounds as plain tiles, then the rest (the partly filled last round, or a launch that is
     // less than one round) as equal shares of (tile, K-stage) units
-    if (tiles > streamk_tail) {
-      d.tile_count = tiles - streamk_tail;
-      if (int rc = launch_cfg<T, 128, 2, 4, KS, 0>(d, d.tile_count, relu, res, s)) return rc;
-    }
     d.tile_begin = tiles - streamk_tail;
     d.tile_count = streamk_tail;
-    return launch_cfg<T, 128, 2, 4, KS, 2>(d, kResident, relu, res, s);
+    return launch_cfg<T, 128, 2, 4, KS, 2>(d, d.tile_begin + kResident, relu, res, s);
   }
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
@@ -407,13 +409,13 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
                  es * ((double)p.B * p.H * p.W * p.Cin + (double)p.Cout * d.K +
                        (double)M * p.Cout * (p.res ? 2.0 : 1.0)));
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide -- except that a
-  // launch of 256..511 wide tiles with a long K loop runs wide as ONE stream-K round (block 4 at
+  // launch of 256..511 wide tiles (230 measured: no gain) with a long K loop runs wide as ONE stream-K round (block 4 at
   // batch 16, 720p: 460 wide tiles, or 920 narrow ones = 1.8 rounds, both 90 % full otherwise).
   const long tiles128 = p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
   const int kt_all = d.K / bke;
   const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
   const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes;
-  const bool streamk_all = streamk_ok && tiles128 >= kResident / 4 && tiles128 < kResident && kt_all >= 32;
+  const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
   const bool wide = g_conv_variant != 4 && (tiles128 >= kResident || streamk_all);
   d.ntiles = p.Cout / (wide ? 128 : 64);
   d.ksplit = 1;
@@ -430,9 +432,10 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
     if (ks > 1 && need <= p.splitk_scratch_bytes && tiles <= kSplitKMaxTiles) d.ksplit = ks;
   }
   // Stream-K tail for the big 128-wide launches: only when the last round is clearly under-filled,
-  // every workgroup's share is at least two K stages, and K rows are >= 4.5 KiB (the 3x3 convs of
-  // blocks 2-3 at batch 16, 720p: -5.5 % / -6 % per launch).  Measured on the same layers' 1x1
-  // neighbours (K rows of 2-4 KiB) the partial tiles, 64 KiB each way, cost more than the tail saves.
+  // every workgroup's share is at least two K stages, and K rows are >= 4 KiB (batch 16, 720p: the
+  // 3x3 convs of blocks 2-3 -7 %, block 4's shortcut -5 %, block 3's 1024->256 convs -1.6 %).
+  // With K rows of 2 KiB the partial tiles, 64 KiB each way, cost more than the tail saves
+  // (measured +3..7 % on those layers).
   // (Measured and rejected: the same tail treatment for the 64-wide tiles of block 1 -- K rows of
   // 2.3 KiB, shares of ~9 stages -- lost 2-6 % per launch.)
   int streamk_tail = 0;
@@ -440,8 +443,12 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
     streamk_tail = (int)tiles;
   } else if (streamk_ok && wide && d.ksplit == 1 && tiles > kResident) {
     const int r = (int)(tiles % kResident);
-    if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 36 && (long)r * kt_all >= 2L * kResident) streamk_tail = r;
+    if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 32 && (long)r * kt_all >= 2L * kResident) streamk_tail = r;
   }
+  // (Measured and rejected: running a sliver of a last round -- 16-64 tiles after 7-28 full rounds,
+  // blocks 1-3 -- as a separate split-K launch.  The hardware does not run tiles in lock-step rounds,
+  // and the drain between the two launches costs more than the sliver: every such layer got 1-5 %
+  // slower.)
   if (p.prec == kF32)
     return p.ksize == 1 ? launch_ks<float, 1>(d, wide, streamk_tail, p.relu != 0, res, s)
                         : launch_ks<float, 3>(d, wide, streamk_tail, p.relu != 0, res, s);

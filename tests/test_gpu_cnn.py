@@ -131,7 +131,9 @@ def test_split_k_reduction_is_exact_and_deterministic():
                                           # whole launch as one stream-K round: 450 and 460 wide tiles
                                           (3, 1, 256, 256, 45, 80, 8), (1, 1, 1024, 512, 23, 40, 16),
                                           # 64-wide tiles, several rounds: plain path
-                                          (3, 1, 64, 64, 90, 160, 6)]:
+                                          (3, 1, 64, 64, 90, 160, 6),
+                                          # 16 wide / 20 narrow tiles left over after full rounds
+                                          (1, 1, 256, 1024, 90, 160, 4), (3, 1, 64, 64, 266, 256, 1)]:
         x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
         K = k * k * cin
         wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
