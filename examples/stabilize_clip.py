@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--ckpt", default=None, help="reference checkpoint directory (with its `checkpoints` index)")
     args = ap.parse_args()
     import inputs
-    frames = inputs.smooth_frames(1, args.frames, args.height, args.width).astype(np.float64)  # frame / 255.
+    # stands in for the decoded video: BGR uint8 frames of another size (eval.py:76-81 resizes them)
+    frames = (inputs.smooth_frames(1, args.frames, args.height * 3 // 2, args.width * 3 // 2) * 255).astype(np.uint8)
+    frames = np.ascontiguousarray(frames[..., ::-1])
 
     sess = Session()                                              # eval.py:46  tf.Session(...)
     net = StabNet(args.height, args.width)                        # eval.py:50
@@ -39,7 +41,8 @@ def main():
     else:
         net.load_weights(make_synthetic_weights(seed=0))
     t0 = time.perf_counter()
-    stabilised, side_by_side = stabilize_clip(net, sess, frames, side_by_side=True)   # eval.py:93-124
+    stabilised, side_by_side = stabilize_clip(net, sess, frames, side_by_side=True, channel_order="bgr",
+                                              as_uint8=True)                       # eval.py:76-124
     dt = time.perf_counter() - t0
     print("stabilised %d frames of %dx%d in %.3f s (%.1f frames/s, autoregressive, batch 1)"
           % (len(stabilised), args.width, args.height, dt, len(stabilised) / dt))
