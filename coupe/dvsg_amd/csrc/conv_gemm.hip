@@ -26,6 +26,13 @@
 // stores (and residual loads) per MFMA block per lane; instead the accumulators are transposed
 // through the idle staging LDS so every thread moves 4 consecutive channels (float4 / 4 x f16).
 //
+// (Measured and rejected alternatives to this epilogue, batch 16 at 720p: storing straight from the
+// accumulators -- 16 dword stores per block, or, with the MFMA operands swapped so a lane holds 4
+// consecutive channels of one pixel, 4 x 16-byte stores of 32 bytes per pixel per instruction --
+// was 3-17 % slower per layer; persistent workgroups that put the next tile's first K stage in
+// flight before the current tile's last one, with the transpose squeezed into the one free stage
+// buffer in two 64-row rounds, gained 7 % on the K = 64 layers and lost 2-5 % everywhere else.)
+//
 // Work decomposition (MODE):
 //   0  one workgroup per output tile.
 //   1  split-K: a launch with too few tiles for the chip (batch 1-2) gives each tile to `ksplit`
