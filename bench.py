@@ -246,13 +246,21 @@ def main():
                          "avg_launch_ms": total_ms / max(launches, 1),
                          "algorithmic_per_launch": (flops if cls <= 2 else nbytes) / max(launches, 1),
                          "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
+        if (B, H, W) == (16, 720, 1280):
+            which = "configs[1]"
+        elif (B, H, W, args.precision) == (32, 2160, 3840, "f16"):
+            which = "configs[4]"
+        elif world > 1 and (B * world, H, W) == (512, 720, 1280):
+            which = "configs[3]"
+        else:
+            which = "non-BASELINE shape"
         line = {
-            "metric": "stabilized frames/sec (1280x720 RGB)", "value": frames / elapsed, "unit": "frames/s",
+            "metric": "stabilized frames/sec (%dx%d RGB)" % (W, H), "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU"
-                                   % (B, W, H),
+            "config": {"workload": "%s: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU"
+                                   % (which, B, W, H),
                        "batch_per_gpu": B, "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
                        "gather": bool(dist is not None and not args.no_gather), "streams_per_gpu": args.streams,
                        "weights": "synthetic seed 0 (reference ships no checkpoint)"},
