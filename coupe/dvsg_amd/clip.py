@@ -6,11 +6,13 @@
   (config.py:48), and the stabilised frame is written back into the history (eval.py:116-120).
   That write-back makes frame t depend on stabilised frame t-1, so ONE clip cannot be sharded
   across GPUs ("replicas only": different clips on different GPUs).
-* `shard_range` / `stabilize_windows_sharded` cover the case that does shard: independent
-  windows (BASELINE.json configs[3]; the teacher-forced regime of eval_train.py).  Rank r owns
-  a contiguous block of windows, there is no data-path collective, and the stabilised frames
-  are gathered to one rank at the end (RCCL over xGMI on GPUs; any torch.distributed backend
-  works -- the CPU tests use gloo).
+* `shard_range` / `sharded_map` / `stabilize_windows_sharded` cover the case that does shard:
+  independent windows (BASELINE.json configs[3]).  Rank r owns a contiguous block of windows,
+  there is no data-path collective, and the stabilised frames are gathered to one rank at the end
+  (RCCL over xGMI on GPUs; any torch.distributed backend works -- the CPU tests use gloo).
+* `stabilize_clip_teacher_forced` is the reference's other driver, eval_train.py:115-165, whose
+  history frames come from the ground-truth stable clip: its windows ARE independent, so a clip
+  runs batched and sharded over the GPUs of a node.
 """
 import numpy as np
 import torch
@@ -27,38 +29,47 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def sharded_map(n, batch, produce, frame_shape, like, group=None, dst=0):
+    """Run `produce(b0, b1) -> [b1-b0, *frame_shape]` over this rank's contiguous share of `n`
+    independent units in batches of at most `batch`, then gather the results, in unit order, on
+    rank `dst` (None elsewhere).  No collective on the data path; one gather at the end."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n, world, rank)
+    outs = []
+    for b0 in range(lo, hi, batch):
+        outs.append(torch.as_tensor(produce(b0, min(hi, b0 + batch))))
+    ref = outs[0] if outs else like
+    local = torch.cat(outs, 0) if outs else ref.new_zeros((0,) + tuple(frame_shape))
+    if world == 1:
+        return local
+    # gather needs equal shapes: pad every shard to the largest one
+    cap = -(-n // world)
+    padded = local.new_zeros((cap,) + tuple(frame_shape))
+    padded[:local.shape[0]] = local
+    back = padded.device
+    if padded.is_cuda and dist.get_backend(group) != "nccl":
+        padded = padded.cpu()  # rehearsal backends (gloo) gather through host memory; RCCL stays on the device
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    bufs = [t.to(back) for t in bufs]
+    parts = []
+    for r in range(world):
+        rlo, rhi = shard_range(n, world, r)
+        parts.append(bufs[r][:rhi - rlo])
+    return torch.cat(parts, 0)
+
+
 def stabilize_windows_sharded(run_fn, patches_t, u_t, batch=16, group=None, dst=0):
     """Stabilise `patches_t` [N,H,W,21] / `u_t` [N,H,W,3] (every rank passes the same N) with
     the windows sharded over the ranks of `group`; returns [N,H,W,3] on rank `dst`, None
     elsewhere.  `run_fn(patches, u) -> [b,H,W,3]` is the per-batch hot path (e.g.
     `lambda p, u: sess.run(outputs['s_t_pred'], {inputs['patches_t']: p, inputs['u_t']: u})`)."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    N = patches_t.shape[0]
-    lo, hi = shard_range(N, world, rank)
-    outs = []
-    for b0 in range(lo, hi, batch):
-        b1 = min(hi, b0 + batch)
-        outs.append(torch.as_tensor(run_fn(patches_t[b0:b1], u_t[b0:b1])))
-    H, W = u_t.shape[1], u_t.shape[2]
-    like = outs[0] if outs else torch.as_tensor(u_t[:0])
-    local = torch.cat(outs, 0) if outs else like.new_zeros((0, H, W, 3))
-    if world == 1:
-        return local
-    # gather needs equal shapes: pad every shard to the largest one
-    cap = -(-N // world)
-    padded = local.new_zeros((cap, H, W, 3))
-    padded[:local.shape[0]] = local
-    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    parts = []
-    for r in range(world):
-        rlo, rhi = shard_range(N, world, r)
-        parts.append(bufs[r][:rhi - rlo])
-    return torch.cat(parts, 0)
+    return sharded_map(patches_t.shape[0], batch, lambda b0, b1: run_fn(patches_t[b0:b1], u_t[b0:b1]),
+                       (u_t.shape[1], u_t.shape[2], 3), torch.as_tensor(u_t[:0]), group, dst)
 
 
 def window_index_table(n_frames, skip_length=SKIP_LENGTH):
@@ -163,3 +174,94 @@ def stabilize_clip(model, session, frames, skip_length=SKIP_LENGTH, side_by_side
         out = out.cpu().numpy()
         side = side.cpu().numpy() if side is not None else None
     return (out, side) if side_by_side else out
+
+
+def teacher_forced_index_table(n_frames, skip_length=SKIP_LENGTH):
+    """eval_train.py:137-165 as an index table.  There the history is never the network's own
+    output: the first 32 unstable frames are replaced by the stable (ground-truth) ones up front
+    (:137-138) and every processed unstable frame is replaced by its stable twin (:162), so step k
+    (frame k + 32) sees stable frames in every slot but the last.  With a pool of 2 N frames --
+    [0, N) unstable, [N, 2N) stable -- entry [k, s] = N + k + skip[s], and [k, -1] = k + 32.
+    The windows do not depend on each other: they shard over GPUs.  Returns int32 [N-32, S]."""
+    skip = np.asarray(skip_length, dtype=np.int64)
+    if skip.ndim != 1 or skip.size < 1 or skip[0] != 0 or np.any(np.diff(skip) <= 0):
+        raise ValueError("skip_length must start at 0 and increase strictly (config.py:48)")
+    N, span = int(n_frames), int(skip[-1])
+    if N <= span:
+        raise ValueError("eval_train.py needs more than %d frames, got %d" % (span, N))
+    k = np.arange(N - span, dtype=np.int64)[:, None]
+    table = N + k + skip[None, :]
+    table[:, -1] = k[:, 0] + span
+    return table.astype(np.int32)
+
+
+def _frames_to_pool(fr, pool, h, w, flip, what):
+    """uint8 / float frames [n,h0,w0,3] on the device -> float32 [n,h,w,3] slice of the pool."""
+    from . import _lib
+    from ._tensor import ptr, stream
+    n = int(fr.shape[0])
+    if fr.dtype == torch.uint8:
+        if tuple(fr.shape[1:3]) == (h, w):
+            _lib.call("dvsg_frames_u8_to_f32", ptr(fr), n * h * w, flip, ptr(pool), stream())
+        else:
+            _lib.call("dvsg_frames_resize_u8_f32", ptr(fr), n, int(fr.shape[1]), int(fr.shape[2]), flip, ptr(pool),
+                      h, w, 0, 0, 0, stream())
+    elif fr.dtype.is_floating_point:
+        if tuple(fr.shape[1:3]) != (h, w):
+            raise ValueError("float %s frames must already be [N,%d,%d,3]" % (what, h, w))
+        pool.copy_(fr)
+    else:
+        raise TypeError("%s frames must be uint8 or floating point, got %s" % (what, fr.dtype))
+
+
+def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length=SKIP_LENGTH, channel_order="rgb",
+                                  as_uint8=False, group=None, dst=0):
+    """eval_train.py:115-165 for one pair of clips: every unstable frame k >= 32 is stabilised from
+    the window [stable k-32, k-16, k-8, k-4, k-2, k-1 | unstable k].  The windows are independent,
+    so they run in batches of `batch` and -- with torch.distributed initialised -- shard over the
+    ranks of `group` with no data-path collective; the stabilised frames are gathered on rank
+    `dst` (BASELINE.json configs[3]).  Every rank passes the same clips (frame formats as in
+    `stabilize_clip`) and keeps the whole pool in its HBM.
+
+    Returns [N-32,h,w,3] float32 (or uint8 with as_uint8) on rank `dst` -- NumPy if the clips were
+    NumPy -- and None on the other ranks."""
+    from . import _lib
+    from ._tensor import device, ptr, stream
+    if channel_order not in ("rgb", "bgr"):
+        raise ValueError("channel_order must be 'rgb' or 'bgr'")
+    if model.locnet is None:
+        raise _lib.DvsgError("StabNet has no weights: call load_weights()/load_ckpt() first")
+    flip = 1 if channel_order == "bgr" else 0
+    host = not isinstance(unstable, torch.Tensor)
+    dev = device()
+    un = (torch.as_tensor(np.ascontiguousarray(unstable)) if host else unstable).to(dev).contiguous()
+    st = (torch.as_tensor(np.ascontiguousarray(stable)) if not isinstance(stable, torch.Tensor) else stable).to(dev).contiguous()
+    if un.dim() != 4 or un.shape[3] != 3 or st.shape != un.shape:
+        raise ValueError("unstable and stable clips must both be [N,h,w,3]")
+    N, h, w, S = int(un.shape[0]), model.h, model.w, len(skip_length)
+    span = int(skip_length[-1])
+    table = torch.from_numpy(teacher_forced_index_table(N, skip_length)).to(dev)
+    pool = torch.empty((2 * N, h, w, 3), dtype=torch.float32, device=dev)
+    _frames_to_pool(un, pool[:N], h, w, flip, "unstable")
+    _frames_to_pool(st, pool[N:], h, w, flip, "stable")
+    patches = torch.empty((batch, h, w, 3 * S), dtype=torch.float32, device=dev)
+    F = torch.empty((batch, model.param_dim, 2), dtype=torch.float32, device=dev)
+
+    def produce(b0, b1):
+        b = b1 - b0
+        _lib.call("dvsg_window_gather_f32", ptr(pool), 2 * N, h, w, ptr(table[b0]), b, S, ptr(patches), stream())
+        out = torch.empty((b, h, w, 3), dtype=torch.float32, device=dev)
+        # u_t of windows b0..b1 are the consecutive unstable frames b0+32 .. b1+32: a slice of the pool
+        model.locnet.stabilize(patches[:b], pool[b0 + span:b1 + span], out, F[:b], n_streams=model.n_streams,
+                               precision=model.precision)
+        if not as_uint8:
+            return out
+        out8 = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)
+        _lib.call("dvsg_frames_f32_to_u8", ptr(out), b, h, w, flip, ptr(out8), w, 0, stream())
+        return out8
+
+    like = torch.empty((0, h, w, 3), dtype=torch.uint8 if as_uint8 else torch.float32, device=dev)
+    res = sharded_map(N - span, batch, produce, (h, w, 3), like, group, dst)
+    if res is not None and host:
+        res = res.cpu().numpy()
+    return res

@@ -73,3 +73,21 @@ def window_index_trace(n_frames, skip_length=(0, 16, 24, 28, 30, 31, 32)):
                 total[i] = s
         idx = idx + 1                                             # :124
     return trace
+
+
+def teacher_forced_trace(n_frames, skip_length=(0, 16, 24, 28, 30, 31, 32)):
+    """Which frame each window slot holds at each step of eval_train.py:137-165, by running the
+    reference's array manipulation on labels: ('u', i) unstable frame i, ('t', i) stable frame i."""
+    skip = np.array(skip_length)
+    span = int(skip[-1] - skip[0])
+    unstab = [('u', i) for i in range(n_frames)]
+    stab = [('t', i) for i in range(n_frames)]
+    for i in range(span):                                          # :137-138
+        unstab[i] = stab[i]
+    idx = skip.copy()
+    trace = []
+    for frame_idx in range(span, n_frames):                        # :146
+        trace.append([unstab[j] for j in idx])                     # :148
+        unstab[idx[-1]] = stab[idx[-1]]                            # :162
+        idx = idx + 1                                              # :165
+    return trace

@@ -88,3 +88,25 @@ def eval_clip(weights, frames, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32)):
         sbs.append(side)
         sample_idx = sample_idx + 1                                  # :124
     return np.stack(outs), np.stack(sbs)
+
+
+def eval_train_clip(weights, unstab, stab, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32)):
+    """eval_train.py:137-165 on in-memory clips [N,h,w,3] float (RGB, /255, resized): the history
+    is teacher-forced from the stable clip.  Returns stabilised frames [N-32,h,w,3] float32."""
+    skip_length = np.array(skip_length)
+    span = int(skip_length[-1] - skip_length[0])
+    total_stab = np.array([np.asarray(f, dtype=np.float64) for f in stab])
+    total_unstab = np.array([np.asarray(f, dtype=np.float64) for f in unstab])
+    for i in range(span):                                           # :137-138
+        total_unstab[i] = total_stab[i]
+    net = StabNet(h, w)
+    outs = []
+    sample_idx = skip_length.copy()
+    for frame_idx in range(span, len(total_unstab)):                # :146
+        batch = total_unstab[sample_idx]                            # :148
+        batch = np.expand_dims(np.concatenate(batch, axis=2), 0)    # :149
+        s_t_pred = np.squeeze(net.run(weights, batch.astype(F32), batch[:, :, :, 18:].astype(F32))[0])  # :151-155
+        total_unstab[sample_idx[-1]] = total_stab[sample_idx[-1]]   # :162
+        outs.append(s_t_pred.astype(F32))
+        sample_idx = sample_idx + 1                                 # :165
+    return np.stack(outs)

@@ -5,7 +5,7 @@ OpenCV's published INTER_LINEAR definition, not from running it."""
 import numpy as np
 import pytest
 
-from coupe.dvsg_amd.clip import SKIP_LENGTH, window_index_table
+from coupe.dvsg_amd.clip import SKIP_LENGTH, teacher_forced_index_table, window_index_table
 from oracle import frames as oframes
 
 
@@ -57,3 +57,14 @@ def test_read_frame_flips_bgr_and_scales():
     bgr[..., 0], bgr[..., 2] = 255, 51
     f = oframes.read_frame(bgr, 6, 4)
     assert f.dtype == np.float64 and np.array_equal(f[0, 0], [0.2, 0.0, 1.0])
+
+
+@pytest.mark.parametrize("n,skip", [(33, SKIP_LENGTH), (40, SKIP_LENGTH), (97, SKIP_LENGTH), (6, (0, 2, 3))])
+def test_teacher_forced_table_replays_eval_train(n, skip):
+    trace = oframes.teacher_forced_trace(n, skip)
+    want = np.array([[i if kind == 'u' else n + i for kind, i in row] for row in trace])
+    got = teacher_forced_index_table(n, skip)
+    assert got.dtype == np.int32 and got.shape == (n - skip[-1], len(skip)) and np.array_equal(got, want)
+    assert np.all(got[:, :-1] >= n) and np.all(got[:, -1] < n)     # history: stable clip; current frame: unstable
+    with pytest.raises(ValueError):
+        teacher_forced_index_table(skip[-1], skip)

@@ -117,3 +117,71 @@ def test_uint8_clip_in_uint8_clip_out(synthetic_weights):
     assert np.array_equal(fout64, fout) and np.array_equal(fside[:, :, :W], rside[:, :, :W, ::-1])
     with pytest.raises(ValueError):
         stabilize_clip(model, None, frames[:, :-1])
+
+
+def test_teacher_forced_clip_matches_eval_train(synthetic_weights):
+    """eval_train.py:137-165: independent windows (history from the stable clip), run batched."""
+    from coupe.dvsg_amd.clip import stabilize_clip_teacher_forced
+    from coupe.dvsg_amd.model import StabNet
+    H, W, N = 32, 48, 37
+    stab = inputs.smooth_frames(6001, N, H, W)
+    unstab = np.roll(stab, 2, axis=2) * 0.9 + 0.05
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    ref = omodel.eval_train_clip(synthetic_weights, unstab, stab, H, W)
+    for batch in (2, 16):
+        out = stabilize_clip_teacher_forced(model, unstab, stab, batch=batch)
+        assert out.shape == (N - 32, H, W, 3) and out.dtype == np.float32
+        assert np.abs(out - ref).max() < 2e-2 and np.median(np.abs(out - ref)) < 1e-5
+    u8 = stabilize_clip_teacher_forced(model, (unstab * 255).astype(np.uint8), (stab * 255).astype(np.uint8), batch=3,
+                                       as_uint8=True)
+    assert u8.dtype == np.uint8 and u8.shape == (N - 32, H, W, 3)
+    ref8 = omodel.eval_train_clip(synthetic_weights, (unstab * 255).astype(np.uint8) / 255.,
+                                  (stab * 255).astype(np.uint8) / 255., H, W)
+    diff = np.abs(u8.astype(int) - oframes.to_uint8(ref8).astype(int))
+    assert (diff > 1).mean() < 0.01 and np.median(diff) == 0
+
+
+def _tf_worker(rank, world, port, out_dir):
+    import os
+    import torch
+    import torch.distributed as dist
+    from coupe.dvsg_amd.clip import stabilize_clip_teacher_forced
+    from coupe.dvsg_amd.model import StabNet
+    from coupe.dvsg_amd.weights import make_synthetic_weights
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                       # one-GPU box: both ranks share the card, gather over gloo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, N = 32, 48, 39
+        stab = inputs.smooth_frames(6001, N, H, W)
+        unstab = np.roll(stab, 2, axis=2) * 0.9 + 0.05
+        model = StabNet(H, W).load_weights(make_synthetic_weights(seed=0))
+        out = stabilize_clip_teacher_forced(model, unstab, stab, batch=2)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "out.npy"), out)
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_teacher_forced_clip_sharded_over_two_ranks(tmp_path, synthetic_weights):
+    """The N > 1 path with the real kernels: two processes shard the 7 windows 4 + 3, no data-path
+    collective, one gather -- same frames as a single process."""
+    import socket
+    import torch.multiprocessing as mp
+    from coupe.dvsg_amd.clip import stabilize_clip_teacher_forced
+    from coupe.dvsg_amd.model import StabNet
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_tf_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    H, W, N = 32, 48, 39
+    stab = inputs.smooth_frames(6001, N, H, W)
+    unstab = np.roll(stab, 2, axis=2) * 0.9 + 0.05
+    single = stabilize_clip_teacher_forced(StabNet(H, W).load_weights(synthetic_weights), unstab, stab, batch=2)
+    got = np.load(tmp_path / "out.npy")
+    assert got.shape == single.shape == (N - 32, H, W, 3)
+    assert np.abs(got - single).max() <= 1e-6
