@@ -51,7 +51,15 @@ __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ xi
       const int b = e / kDenseKC, k = e % kDenseKC;
       float v = 0.f;
       if (b < B && k < kn) {
-        for (int s = 0; s < s_in; ++s) v += xin[((size_t)b * s_in + s) * K + kbase + k];
+        // loads four at a time (independent, in flight together), adds in the original order
+        const float *xp = xin + (size_t)b * s_in * K + kbase + k;
+        int s = 0;
+        for (; s + 4 <= s_in; s += 4) {
+          const float t0 = xp[(size_t)s * K], t1 = xp[(size_t)(s + 1) * K], t2 = xp[(size_t)(s + 2) * K],
+                      t3 = xp[(size_t)(s + 3) * K];
+          v += t0; v += t1; v += t2; v += t3;
+        }
+        for (; s < s_in; ++s) v += xp[(size_t)s * K];
         v *= scale_in;
         if (bias_in) v += bias_in[kbase + k];
         if (lrelu_in) v = v >= 0.f ? v : 0.2f * v;  // networks.py:31
@@ -60,10 +68,23 @@ __global__ __launch_bounds__(256) void dense_kernel(const float *__restrict__ xi
     }
     __syncthreads();
     if (col < N) {
-      for (int k = kg; k < kn; k += 4) {
-        const float w = Wm[(size_t)(kbase + k) * N + col];
+      // eight weight loads in flight per thread (one at a time made the layer latency-bound:
+      // 64 dependent L2 round trips); the fmaf chain per output keeps its k order
+      for (int k0 = kg; k0 < kn; k0 += 32) {
+        float w[8];
 #pragma unroll
-        for (int b = 0; b < kDenseMaxB; ++b) acc[b] = fmaf(xs[b][k], w, acc[b]);
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 4 * u;
+          w[u] = k < kn ? Wm[(size_t)(kbase + k) * N + col] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 4 * u;
+          if (k < kn) {
+#pragma unroll
+            for (int b = 0; b < kDenseMaxB; ++b) acc[b] = fmaf(xs[b][k], w[u], acc[b]);
+          }
+        }
       }
     }
   }
