@@ -150,16 +150,21 @@ void conv_gemm_kernel(ConvGemmDev p) {
       wsrc[i] = pw + (size_t)(n0 + row) * p.K + CHE * (lpos ^ ((row >> 1) & 7));
     }
 
-    // (kh, kw, c0) of the stage being issued advance incrementally: no integer division in the loop
-    int s_kh = 0, s_kw = 0, s_k0 = kt0 * BKE, s_c0 = s_k0;
-    if (MODE != 0 && KS > 1) {
-      const int tap = s_k0 / p.Cin;
-      s_c0 = s_k0 - tap * p.Cin;
+    // K order of a 3x3 conv: channel chunk OUTER, the 9 taps INNER (k order is free as long as A and
+    // the weights agree: the weight stage of (tap, c0) is just column tap * Cin + c0 of the same
+    // matrix).  Consecutive stages then re-read the same input lines shifted by one pixel / one row,
+    // i.e. out of L1 / L2, instead of coming back to them one tap (Cin / 32 stages x 64 workgroups x
+    // 16 KB, more than an XCD's L2) later.  (kh, kw, c0) advance incrementally: no division in the loop.
+    int s_kh = 0, s_kw = 0, s_c0 = kt0 * BKE;
+    if (KS > 1) {
+      const int chunk = kt0 / (KS * KS), tap = kt0 - chunk * (KS * KS);
+      s_c0 = chunk * BKE;
       s_kh = tap / KS;
       s_kw = tap - s_kh * KS;
     }
     auto issue_stage = [&](int buf) __attribute__((always_inline)) {
       const T *xa = px + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+      const int wk = KS > 1 ? (s_kh * KS + s_kw) * p.Cin + s_c0 : s_c0;
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
         const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
@@ -168,16 +173,18 @@ void conv_gemm_kernel(ConvGemmDev p) {
       }
 #pragma unroll
       for (int i = 0; i < BG; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + s_k0),
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + wk),
                                          (lptr_t)(Bs + (buf * BN + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
-      s_k0 += BKE;
-      s_c0 += BKE;
-      if (KS > 1 && s_c0 == p.Cin) {
-        s_c0 = 0;
+      if (KS > 1) {
         if (++s_kw == KS) {
           s_kw = 0;
-          ++s_kh;
+          if (++s_kh == KS) {
+            s_kh = 0;
+            s_c0 += BKE;
+          }
         }
+      } else {
+        s_c0 += BKE;
       }
     };
 
