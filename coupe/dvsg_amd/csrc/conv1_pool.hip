@@ -48,7 +48,9 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  int blk = blockIdx.x;
+  // each XCD takes a contiguous range of tiles: the 3-4 output rows that share an input row run on
+  // the same L2 (consecutive block ids are dealt round-robin over the 8 XCDs)
+  int blk = xcd_remap(blockIdx.x, gridDim.x);
   const int wt_i = blk % wtiles;
   blk /= wtiles;
   const int ho = blk % Ho;
@@ -229,7 +231,7 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  int blk = blockIdx.x;
+  int blk = xcd_remap(blockIdx.x, gridDim.x);  // see conv1_kernel
   const int wt_i = blk % wtiles;
   blk /= wtiles;
   const int ho = blk % Ho;
