@@ -174,7 +174,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, T *__restrict__ y, int H, int W,
                                                      int C4, int Ho, int Wo, int pad_top, int pad_left,
                                                      size_t total) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+  // one element per thread; each XCD takes a contiguous range of blocks so that the output rows
+  // sharing an input row (3x3 window, stride 2) read it out of the same L2
+  {
+    const size_t e = (size_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (e >= total) return;
     const int c4 = (int)(e % C4);
     size_t t = e / C4;
     const int wo = (int)(t % Wo);
@@ -385,7 +389,8 @@ int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C,
   DVSG_REQUIRE(C % 4 == 0, "maxpool: C=%d must be a multiple of 4", C);
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
   const size_t want = (total + 255) / 256;
-  const int blocks = (int)(want < 16384 ? want : 16384);
+  DVSG_REQUIRE(want < (1u << 31), "maxpool: %zu blocks do not fit a grid", want);
+  const int blocks = (int)want;
   ProfScope prof(kClsMaxpool, s, 0.0, (double)elem_size(prec) * C * ((double)B * H * W + (double)B * Ho * Wo));
   if (prec == kF16)
     hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16 *>(x),
