@@ -71,6 +71,7 @@ struct ConvGemmDev {
   int stride, pad;
   int res_H, res_W, res_stride;
   int M, K, mtiles, ntiles;
+  int mt_fast;     // tile order, see run_segment
 };
 
 template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, int MODE>
@@ -114,7 +115,16 @@ void conv_gemm_kernel(ConvGemmDev p) {
   // `ticket_idx`.  n_contrib == 1: plain tile.
   auto run_segment = [&](int tile, int kt0, int kt1, int n_contrib, int own, int ticket_idx,
                          auto slab_of) __attribute__((always_inline)) {
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    // tile -> (mt, nt): nt fastest by default (neighbouring tiles share the activation panel);
+    // mt fastest when one weight panel is a large part of an XCD's L2 (see launch_conv_gemm)
+    int mt, nt;
+    if (p.mt_fast) {
+      nt = tile / p.mtiles;
+      mt = tile - nt * p.mtiles;
+    } else {
+      mt = tile / p.ntiles;
+      nt = tile - mt * p.ntiles;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- staging: wave `wave` fills row groups g = wave + NW i; lane -> row 8 g + lane / 8,
@@ -432,6 +442,12 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
   const bool wide = g_conv_variant != 4 && (tiles128 >= kResident || streamk_all);
   d.ntiles = p.Cout / (wide ? 128 : 64);
+  // Tile order.  Each XCD runs a contiguous range of tiles.  With nt fastest that range covers every
+  // weight panel, which is right while a panel (BN x K) is small; block 4's 3x3 conv has 2.4 MB
+  // panels, and its stream-K workgroups stream them at 512 different K phases, so each tile fetched
+  // its whole panel past the 4 MB L2 (1.2 GB per launch).  With mt fastest an XCD stays on one or
+  // two panels and re-reads the (much smaller) activations instead.
+  d.mt_fast = d.ntiles > 1 && (size_t)(wide ? 128 : 64) * d.K * elem_size(p.prec) >= ((size_t)2 << 20);
   d.ksplit = 1;
   d.slabs = static_cast<float *>(p.splitk_scratch);
   d.counters = p.splitk_counters;
