@@ -241,8 +241,43 @@ void conv_gemm_kernel(ConvGemmDev p) {
 
     // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
     constexpr int LDC = BN + 4;
+    constexpr int C4 = BN / 4;       // 4-channel groups per tile row
+    constexpr int RSTEP = NT / C4;   // tile rows covered per pass
+    constexpr int NROW = BM / RSTEP; // rows per thread
+    const int col4 = tid % C4, row0 = tid / C4;
+    const int n = n0 + 4 * col4;
     float *Cs = reinterpret_cast<float *>(lds);
-    __syncthreads();
+    const bool reduce = MODE != 0 && n_contrib > 1;
+    // Bias and residual are fetched NOW, before the transpose: their latency runs under the two
+    // barriers and the LDS round trip (the barriers below wait for LDS traffic only, not vmcnt;
+    // loading the residual inside the store loop exposed two L2 / HBM round trips per tile).
+    // Rows past M read row M-1: unconditional loads, the store is what is guarded.
+    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+    float4 rv[NROW];
+    if (RES != 0 && !reduce) {
+#pragma unroll
+      for (int i = 0; i < NROW; ++i) {
+        const int mr = m0 + row0 + i * RSTEP;
+        const int m = mr < p.M ? mr : p.M - 1;
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(pres + roff);
+      }
+    }
+    auto lds_barrier = [&]() __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    lds_barrier();  // everyone is done reading the stage buffers
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -251,13 +286,8 @@ void conv_gemm_kernel(ConvGemmDev p) {
         for (int q = 0; q < 16; ++q)
           Cs[(wm * (BM / WM) + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * LDC + wn * (BN / WN) + ni * 32 + r] =
               acc[mi][ni][q];
-    __syncthreads();
-    constexpr int C4 = BN / 4;       // 4-channel groups per tile row
-    constexpr int RSTEP = NT / C4;   // tile rows covered per pass
-    const int col4 = tid % C4, row0 = tid / C4;
-    const int n = n0 + 4 * col4;
-    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
-    if (MODE != 0 && n_contrib > 1) {
+    lds_barrier();
+    if (reduce) {
       float *mine = slab_of(own);
       for (int row = row0; row < BM; row += RSTEP)
         *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
@@ -277,12 +307,13 @@ void conv_gemm_kernel(ConvGemmDev p) {
       }
       __syncthreads();
     }
-#pragma unroll 4
-    for (int row = row0; row < BM; row += RSTEP) {
+#pragma unroll
+    for (int i = 0; i < NROW; ++i) {
+      const int row = row0 + i * RSTEP;
       const int m = m0 + row;
       if (m >= p.M) break;
       float4 v;
-      if (MODE != 0 && n_contrib > 1) {
+      if (reduce) {
         v = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < n_contrib; ++j) {
           const float4 t = j == own ? *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4)
@@ -294,18 +325,23 @@ void conv_gemm_kernel(ConvGemmDev p) {
       }
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (RES != 0) {
-        size_t roff;
-        if (RES == 1) {
-          roff = (size_t)m * p.Cout + n;
-        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
-          const int wo = m % p.Wo;
-          const int t = m / p.Wo;
-          const int ho = t % p.Ho;
-          const int b = t / p.Ho;
-          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        float4 r4;
+        if (reduce) {  // the finishing contributor of a split tile loads it here
+          size_t roff;
+          if (RES == 1) {
+            roff = (size_t)m * p.Cout + n;
+          } else {
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int b = t / p.Ho;
+            roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+          }
+          r4 = load4(pres + roff);
+        } else {
+          r4 = rv[i];
         }
-        const float4 rv = load4(pres + roff);
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
       }
       if (RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
