@@ -168,6 +168,18 @@ def test_ragged_and_extreme_shapes(net, synthetic_weights, B, H, W):
     assert np.abs(F16 - F_ref).max() < 3e-3
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 200, 320), (2, 288, 512), (5, 150, 270), (7, 96, 416), (4, 360, 640)])
+def test_tile_count_regimes(net, synthetic_weights, B, H, W):
+    """Shapes whose conv launches fall into the different work decompositions (split-K for a
+    handful of tiles, one fat round, whole-launch stream-K, full rounds + stream-K tail, ragged last
+    M tile): F_t against the independent torch-CPU oracle."""
+    from oracle.cnn_torch import TorchLocNet
+    x = inputs.window_frames(977 + B, B, H, W)
+    F = net.forward(x).cpu().numpy()
+    F_ref = TorchLocNet(synthetic_weights).forward(x)
+    assert np.abs(F - F_ref).max() <= 1e-5
+
+
 def test_bad_calls_are_rejected(net):
     import torch
     from coupe.dvsg_amd import DvsgError, _lib
