@@ -225,19 +225,37 @@ void conv_gemm_kernel(ConvGemmDev p) {
       }
     };
 
-    // __syncthreads() carries the vmcnt(0) that retires the DMA of the next stage (and orders
-    // everyone's reads of the buffer about to be refilled).
+    // Both stage buffers are free when a tile starts, so stages 0 AND 1 go in flight together and the
+    // first wait is a counted one (LDS-DMA completes in issue order: "at most one stage's worth
+    // outstanding" means stage 0 has landed).  Issuing stage 1 only after stage 0 had arrived exposed
+    // most of a second L2 / HBM round trip per tile -- a third of the time of a K = 64 tile.
+    // From then on __syncthreads() carries the vmcnt(0) that retires the DMA of the next stage and
+    // orders everyone's reads of the buffer about to be refilled.
     const int KT = kt1 - kt0;
+    constexpr int PER = AG + BG;  // LDS-DMA instructions per wave and stage
     issue_stage(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT - 1; ++kt) {
+    if (KT > 1) {
+      issue_stage(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    compute_stage(0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 1; kt < KT - 1; ++kt) {
+      __syncthreads();
       issue_stage((kt + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       compute_stage(kt & 1);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
     }
-    compute_stage((KT - 1) & 1);
+    if (KT > 1) {
+      __syncthreads();
+      compute_stage((KT - 1) & 1);
+    }
 
     // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
     constexpr int LDC = BN + 4;
