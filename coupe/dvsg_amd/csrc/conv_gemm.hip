@@ -33,6 +33,15 @@
 // flight before the current tile's last one, with the transpose squeezed into the one free stage
 // buffer in two 64-row rounds, gained 7 % on the K = 64 layers and lost 2-5 % everywhere else.)
 //
+// Where the main loop's time goes (ablations at batch 16, 720p, plain tiles): with the LDS-DMA
+// removed the 52 launches of a step take 17.8 ms instead of 19.6, and exactly the same with the DMA
+// left in but the activation addresses folded into a 256 KB (L2-resident) window; removing the
+// per-stage barriers as well changes nothing.  So instruction issue and barriers are free and the
+// 9 % is the service of L2 misses on the activation stream (one stage of lead does not cover it).
+// An L2 prefetch of the stage after next (4-byte LDS-DMA per 8 rows into a scratch corner, counted
+// vmcnt waits so nobody waits for it) made the launches 4 % SLOWER: the miss path, not the lead,
+// is what is short.
+//
 // Work decomposition (MODE):
 //   0  one workgroup per output tile.
 //   1  split-K: a launch with too few tiles for the chip (batch 1-2) gives each tile to `ksplit`
