@@ -39,8 +39,9 @@
 // per-stage barriers as well changes nothing.  So instruction issue and barriers are free and the
 // 9 % is the service of L2 misses on the activation stream (one stage of lead does not cover it).
 // An L2 prefetch of the stage after next (4-byte LDS-DMA per 8 rows into a scratch corner, counted
-// vmcnt waits so nobody waits for it) made the launches 4 % SLOWER: the miss path, not the lead,
-// is what is short.
+// vmcnt waits so nobody waits for it) made the launches 4 % SLOWER, and a third LDS stage for the
+// 64-wide tiles (two stages of lead, still two workgroups per CU) changed nothing: it is not the
+// lead that is short.
 //
 // Work decomposition (MODE):
 //   0  one workgroup per output tile.
