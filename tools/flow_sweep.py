@@ -1,5 +1,8 @@
-import sys, torch, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
+#!/usr/bin/env python3
+"""tf_warp bandwidth against the coherence of the flow field (zero, constant, N(0, 4 px) box-smoothed)."""
+import os, sys, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from coupe.dvsg_amd import _lib
 from warp_bench import timeit
 dev=torch.device('cuda:0'); s=torch.cuda.current_stream().cuda_stream
