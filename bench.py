@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
-KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*>", 2: "conv_gemm_kernel<*,1,*>",
+KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*> + conv3x3_1x1_kernel", 2: "conv_gemm_kernel<*,1,*>",
                   3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel"}
 
 

@@ -42,6 +42,7 @@ SIGNATURES = {
     "dvsg_stabilize_f16": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
+    "dvsg_conv3x3_1x1_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dvsg_frames_u8_to_f32": [_vp, ctypes.c_size_t, _i, _vp, _vp],
     "dvsg_frames_resize_u8_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "dvsg_window_gather_f32": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
@@ -81,9 +82,10 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     _lib = lib
-    # diagnostic A/B switch for kernel experiments (see dvsg_debug_set_option in the header)
-    if os.environ.get("DVSG_CONV_VARIANT"):
-        check(lib.dvsg_debug_set_option(b"conv_variant", int(os.environ["DVSG_CONV_VARIANT"])), "dvsg_debug_set_option")
+    # diagnostic A/B switches for kernel experiments (see dvsg_debug_set_option in the header)
+    for env, opt in (("DVSG_CONV_VARIANT", b"conv_variant"), ("DVSG_FUSE_CONV", b"fuse_conv")):
+        if os.environ.get(env):
+            check(lib.dvsg_debug_set_option(opt, int(os.environ[env])), "dvsg_debug_set_option")
     return lib
 
 

@@ -36,6 +36,24 @@ struct ConvGemm {
 constexpr int kSplitKMaxTiles = 512;                                   // tickets one launch may use
 constexpr size_t kSplitKSlabBytes = (size_t)512 * 2 * 128 * 128 * 4;   // 64 MiB: 512 workgroups x 2 partial 128x128 f32 tiles (stream-K tail)
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
+// conv2 (3x3, Cin -> 64, stride 1/2, pad 1, + bias + ReLU) followed by conv3 (1x1, 64 -> Cout, + bias +
+// residual + ReLU) of a bottleneck unit whose middle width is 64 (block 1), fused: the [M,64]
+// intermediate stays in LDS.  float32 only.
+struct ConvFused {
+  const float *x;      // [B,H,W,Cin]
+  const float *wt2;    // [64][9*Cin]
+  const float *bias2;  // [64]
+  const float *wt3;    // [Cout][64]
+  const float *bias3;  // [Cout]
+  const float *res;    // [B,res_H,res_W,Cout], sampled at (ho*res_stride, wo*res_stride)
+  float *y;            // [B,Ho,Wo,Cout]
+  int B, H, W, Cin, Ho, Wo, Cout;
+  int stride;
+  int res_H, res_W, res_stride;
+};
+bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize);
+int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s);
+void set_fuse_conv(int v);
 void set_conv_variant(int v);   // diagnostic A/B switches (dvsg_debug_set_option)
 void set_conv1_variant(int v);
 

@@ -1,0 +1,299 @@
+// conv2 (3x3, 64 -> 64, stride 1 or 2, + BN + ReLU) and conv3 (1x1, 64 -> C_out, + BN + residual +
+// ReLU) of a block-1 bottleneck unit (networks.py:33-34 -> slim bottleneck_v1) as ONE kernel, float32.
+//
+// Why: conv3 with K = 64 is an HBM-bound layer -- it reads the [M,64] tensor conv2 has just written,
+// a residual and writes 4x as many channels, with 2 K stages of matrix-core work per tile -- and
+// conv2 with N = 64 is matrix-core bound with almost no HBM traffic.  A workgroup's 128 x 64 conv2
+// tile is a COMPLETE left operand for conv3 (its K is conv2's N), so the tile goes from the
+// accumulators through bias + ReLU straight into LDS, in the layout the fragment reads expect, and
+// is multiplied by conv3's weights there: the [M,64] intermediate (2 x 236 MB per unit at batch 16,
+// 720p) never exists, and conv3's residual loads / output stores run under conv2's matrix-core time
+// of the other workgroup on the CU.
+//
+// Phase 1 is conv_gemm_kernel's 64-wide configuration unchanged (8 waves = 4 x 2 tiles of 32 x 32,
+// LDS-DMA staging, XOR-swizzled K-contiguous rows, two stages, channel chunk outer / taps inner).
+// Phase 2 keeps the 128 x 64 tile in the first 32 KiB of LDS as two 32-k stages and streams conv3's
+// weights through the other 32 KiB, 128 output channels at a time (wave tile 32 x 64); each 128-wide
+// result leaves through a 64-row LDS transpose in the weight area (two rounds), 16 bytes per lane.
+#include <algorithm>
+
+#include "cnn_device.h"
+#include "cnn_kernels.h"
+
+namespace dvsg {
+namespace {
+
+constexpr int BM = 128;
+constexpr int ROWB = 128;   // bytes of k per tile row and stage (32 float32)
+constexpr int CMID = 64;    // conv2's output channels = conv3's K
+
+__device__ const floatx4 g_zero16f = {0.f, 0.f, 0.f, 0.f};
+
+struct ConvFusedDev {
+  const float *x;      // [B,H,W,Cin]
+  const float *wt2;    // conv2 [64][9*Cin]
+  const float *bias2;  // [64]
+  const float *wt3;    // conv3 [Cout][64]
+  const float *bias3;  // [Cout]
+  const float *res;    // residual [B,res_H,res_W,Cout]
+  float *y;            // [B,Ho,Wo,Cout]
+  int H, W, Cin, Ho, Wo, Cout;
+  int stride;
+  int res_H, res_W, res_stride;
+  int M, mtiles;
+};
+
+template <int RES>  // 1: residual has the output's shape, 2: subsampled shortcut x[:, ::s, ::s, :]
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv3x3_1x1_kernel(ConvFusedDev p) {
+  constexpr int NW = 8;
+  constexpr int AG = BM / 8 / NW;  // 2 LDS-DMA instructions per wave and stage for the activation tile
+  __shared__ __attribute__((aligned(16))) char lds[65536];
+  char *As = lds;             // phase 1: 2 x 16 KiB activation stages; phase 2: the conv2 tile, 2 x 32 k
+  char *Bs = lds + 32768;     // phase 1: 2 x 8 KiB weight stages
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow8 = lane >> 3, lpos = lane & 7;
+  const int sw = (r >> 1) & 7;
+  const int K1 = 9 * p.Cin;
+  const int KT = K1 / 32;
+
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  const int m0 = xcd_remap(blockIdx.x, p.mtiles) * BM;
+
+  // ---------------------------------------------------------------- phase 1: conv2 tile 128 x 64
+  long a_off[AG];
+  unsigned a_mask[AG];
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    const int row = 8 * (wave + NW * i) + lrow8;
+    const int chunk = lpos ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    const int mm = m < p.M ? m : 0;
+    const int wo = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int ho = t % p.Ho;
+    const int b = t / p.Ho;
+    const int hi0 = ho * p.stride - 1, wi0 = wo * p.stride - 1;
+    a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + 4 * chunk;
+    unsigned mk = 0;
+    if (m < p.M) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (hi0 + q >= 0 && hi0 + q < p.H) mk |= 1u << q;
+        if (wi0 + q >= 0 && wi0 + q < p.W) mk |= 16u << q;
+      }
+    }
+    a_mask[i] = mk;
+  }
+  const float *wsrc;
+  {
+    const int row = 8 * wave + lrow8;  // 64 weight rows: one DMA instruction per wave
+    wsrc = p.wt2 + (size_t)row * K1 + 4 * (lpos ^ ((row >> 1) & 7));
+  }
+  int s_kh = 0, s_kw = 0, s_c0 = 0;
+  auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+    const float *xa = p.x + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+    const int wk = (s_kh * 3 + s_kw) * p.Cin + s_c0;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
+      const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16f);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + wk), (lptr_t)(Bs + (buf * CMID + 8 * wave) * ROWB), 16, 0, 0);
+    if (++s_kw == 3) {
+      s_kw = 0;
+      if (++s_kh == 3) {
+        s_kh = 0;
+        s_c0 += 32;
+      }
+    }
+  };
+  floatx16 acc1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+  auto compute_stage = [&](int buf) __attribute__((always_inline)) {
+    const char *a_base = As + (buf * BM + wm * 32 + r) * ROWB;
+    const char *b_base = Bs + (buf * CMID + wn * 32 + r) * ROWB;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int co = 16 * ((2 * kb + h) ^ sw);
+      const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_base + co);
+      const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_base + co);
+      acc1 = Frag<float>::mma(a4, b4, acc1);
+    }
+  };
+  auto w3_issue = [&](int half, int s2) __attribute__((always_inline)) {
+    // conv3 weight rows n = 128 half + row, 32-k stage s2: stage 0 -> lds + 48 KiB, stage 1 -> lds + 32 KiB
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 8 * (wave + NW * i) + lrow8;
+      const float *src = p.wt3 + (size_t)(128 * half + row) * CMID + 32 * s2 + 4 * (lpos ^ ((row >> 1) & 7));
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (s2 == 0 ? 49152 : 32768) + 8 * (wave + NW * i) * ROWB),
+                                       16, 0, 0);
+    }
+  };
+  issue_stage(0);
+  issue_stage(1);  // KT >= 18
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AG + 1) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  compute_stage(0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 1; kt < KT - 1; ++kt) {
+    __syncthreads();
+    issue_stage((kt + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_stage(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  w3_issue(0, 0);  // lds + 48 KiB is not used by phase 1: conv3's first weight stage lands under the last conv2 stage
+  __builtin_amdgcn_sched_barrier(0);
+  compute_stage((KT - 1) & 1);
+
+  // ---------------------------------------------------------------- the tile becomes conv3's left operand
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h.  Lane (r, h) of wave
+  // (wm, wn) holds mid channel k2 = 32 wn + r of 16 pixels: stage wn, 16-byte chunk r >> 2, swizzled like
+  // an LDS-DMA'd row so compute2 below reads it exactly as compute_stage reads an activation stage.
+  const float bmid = p.bias2[32 * wn + r];
+  __syncthreads();  // everyone is done with the phase-1 stage buffers
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int R = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    const float v = fmaxf(acc1[q] + bmid, 0.f);
+    *reinterpret_cast<float *>(lds + (wn * BM + R) * ROWB + 16 * ((r >> 2) ^ ((R >> 1) & 7)) + 4 * (r & 3)) = v;
+  }
+  w3_issue(0, 1);
+
+  // ---------------------------------------------------------------- phase 2: conv3, 128 channels at a time
+  float *Cs = reinterpret_cast<float *>(lds + 32768);  // 64 rows x 128 channels transpose buffer
+  const int col4 = tid & 31, row0 = tid >> 5;          // 32 float4 per row, 16 rows per pass
+  auto lds_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto compute2 = [&](int s2, floatx16 *acc2) __attribute__((always_inline)) {
+    const char *a_base = lds + (s2 * BM + wm * 32 + r) * ROWB;
+    const char *b_base = lds + (s2 == 0 ? 49152 : 32768) + (wn * 64 + r) * ROWB;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int co = 16 * ((2 * kb + h) ^ sw);
+      const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_base + co);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_base + ni * 32 * ROWB + co);
+        acc2[ni] = Frag<float>::mma(a4, b4, acc2[ni]);
+      }
+    }
+  };
+  const int nhalves = p.Cout / 128;
+  for (int half = 0; half < nhalves; ++half) {
+    floatx16 acc2[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc2[ni][q] = 0.f;
+    // weight stage 0 has landed once at most stage 1's two DMA instructions are outstanding
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // (first half: the conv2 tile written above is visible too)
+    asm volatile("" ::: "memory");
+    compute2(0, acc2);
+    __syncthreads();  // weight stage 1 landed
+    compute2(1, acc2);
+    // epilogue of this half: two rounds of 64 rows through the (now idle) weight area
+    const int n = 128 * half + 4 * col4;
+    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias3 + n);
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      // residual of this round's rows is fetched before the transpose (its latency runs under it)
+      float4 rv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mr = m0 + 64 * rho + row0 + 16 * i;
+        const int m = mr < p.M ? mr : p.M - 1;
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(p.res + roff);
+      }
+      lds_barrier();  // weights of this half consumed / previous round's rows read
+      if ((wm >> 1) == rho) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            Cs[((wm & 1) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 128 + wn * 64 + ni * 32 + r] = acc2[ni][q];
+      }
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 16 * i;
+        const int m = m0 + 64 * rho + row;
+        if (m < p.M) {
+          float4 v = *reinterpret_cast<const float4 *>(Cs + row * 128 + 4 * col4);
+          v.x = fmaxf(v.x + bias4.x + rv[i].x, 0.f);
+          v.y = fmaxf(v.y + bias4.y + rv[i].y, 0.f);
+          v.z = fmaxf(v.z + bias4.z + rv[i].z, 0.f);
+          v.w = fmaxf(v.w + bias4.w + rv[i].w, 0.f);
+          store4(p.y + (size_t)m * p.Cout + n, v);
+        }
+      }
+    }
+    if (half + 1 < nhalves) {
+      lds_barrier();  // the transpose buffer has been read: the next 128 weight rows may land in it
+      w3_issue(half + 1, 0);
+      w3_issue(half + 1, 1);
+    }
+  }
+}
+
+int g_fuse_conv = 1;  // dvsg_debug_set_option("fuse_conv", 0) turns the fused block-1 path off
+
+}  // namespace
+
+void set_fuse_conv(int v) { g_fuse_conv = v; }
+bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize) {
+  return g_fuse_conv != 0 && prec == kF32 && ksize == 3 && Cmid == CMID && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0;
+}
+
+int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
+  DVSG_REQUIRE(p.Cin % 32 == 0 && p.Cin >= 64 && p.Cout % 128 == 0, "conv3x3_1x1: Cin=%d must be a multiple of 32 (>= 64), Cout=%d of 128",
+               p.Cin, p.Cout);
+  DVSG_REQUIRE(p.res, "conv3x3_1x1: the unit output needs its residual");
+  const long M = (long)p.B * p.Ho * p.Wo;
+  DVSG_REQUIRE(M > 0 && M < (1L << 31) - BM, "conv3x3_1x1: M=%ld out of range", M);
+  ConvFusedDev d;
+  d.x = p.x; d.wt2 = p.wt2; d.bias2 = p.bias2; d.wt3 = p.wt3; d.bias3 = p.bias3; d.res = p.res; d.y = p.y;
+  d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
+  d.stride = p.stride;
+  d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;
+  d.M = (int)M;
+  d.mtiles = (int)((M + BM - 1) / BM);
+  const int res = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2;
+  // algorithmic work: both contractions; bytes = input + both weight sets + residual + output, once each
+  ProfScope prof(kClsConv3x3, s, 2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID,
+                 4.0 * ((double)p.B * p.H * p.W * p.Cin + (double)CMID * 9 * p.Cin + (double)p.Cout * CMID +
+                        2.0 * (double)M * p.Cout));
+  if (res == 1)
+    hipLaunchKernelGGL(conv3x3_1x1_kernel<1>, dim3(d.mtiles), dim3(512), 0, s, d);
+  else
+    hipLaunchKernelGGL(conv3x3_1x1_kernel<2>, dim3(d.mtiles), dim3(512), 0, s, d);
+  return check_launch("conv3x3_1x1_kernel");
+}
+
+}  // namespace dvsg

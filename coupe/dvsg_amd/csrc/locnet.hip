@@ -293,8 +293,17 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
       res_h = ho; res_w = wo; res_stride = 1;
     }
     DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
-    DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
-    DVSG_RUN(run_conv(prec, u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, ws, &launch_idx, s));
+    if (conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize)) {  // block 1: conv2 + conv3 in one kernel
+      ConvFused f;
+      f.x = reinterpret_cast<const float *>(ws.r1); f.wt2 = u.c2.wt; f.bias2 = u.c2.bias; f.wt3 = u.c3.wt; f.bias3 = u.c3.bias;
+      f.res = static_cast<const float *>(res); f.y = reinterpret_cast<float *>(Y);
+      f.B = B; f.H = h; f.W = w; f.Cin = u.c2.cin; f.Ho = ho; f.Wo = wo; f.Cout = u.c3.cout;
+      f.stride = u.c2.stride; f.res_H = res_h; f.res_W = res_w; f.res_stride = res_stride;
+      DVSG_RUN(launch_conv3x3_1x1(f, s));
+    } else {
+      DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+      DVSG_RUN(run_conv(prec, u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, ws, &launch_idx, s));
+    }
     h = ho; w = wo;
     DVSG_TAP(stage, Y, h, w, u.depth);
     ++stage;
@@ -512,6 +521,21 @@ int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const v
                       scratch_bytes, stream);
 }
 
+int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, const float *wt3, const float *bias3,
+                         const float *res, float *y, int B, int H, int W, int Cin, int Cout, int stride, int res_stride,
+                         void *stream) {
+  DVSG_REQUIRE(x && wt2 && bias2 && wt3 && bias3 && res && y, "dvsg_conv3x3_1x1_f32: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && res_stride >= 1,
+               "dvsg_conv3x3_1x1_f32: bad shape B=%d H=%d W=%d stride=%d res_stride=%d", B, H, W, stride, res_stride);
+  ConvFused f;
+  f.x = x; f.wt2 = wt2; f.bias2 = bias2; f.wt3 = wt3; f.bias3 = bias3; f.res = res; f.y = y;
+  f.B = B; f.H = H; f.W = W; f.Cin = Cin; f.Cout = Cout;
+  f.Ho = (H - 1) / stride + 1; f.Wo = (W - 1) / stride + 1;
+  f.stride = stride;
+  f.res_H = (f.Ho - 1) * res_stride + 1; f.res_W = (f.Wo - 1) * res_stride + 1; f.res_stride = res_stride;
+  return launch_conv3x3_1x1(f, as_stream(stream));
+}
+
 int dvsg_debug_set_option(const char *name, int value) {
   DVSG_REQUIRE(name, "dvsg_debug_set_option: NULL name");
   if (std::strcmp(name, "conv_variant") == 0) {
@@ -520,6 +544,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "conv1_variant") == 0) {
     set_conv1_variant(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "fuse_conv") == 0) {
+    set_fuse_conv(value);
     return DVSG_OK;
   }
   return fail(DVSG_ERR_INVALID_ARG, "dvsg_debug_set_option: unknown option %s", name);

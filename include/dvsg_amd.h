@@ -221,7 +221,15 @@ int dvsg_frames_f32_to_u8(const float *src, int n, int H, int W, int channel_fli
 int dvsg_frames_f64_to_u8(const double *src, int n, int H, int W, int channel_flip, uint8_t *dst, int dst_W,
                           int dst_x0, void *stream);
 
-/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant").  Process-global. */
+/* Second building block: conv2 (3x3, pad 1, stride 1 or 2, Cin -> 64, + bias + ReLU) and conv3 (1x1,
+ * 64 -> Cout, + bias + residual + ReLU) of a block-1 bottleneck unit as one kernel; the [M,64]
+ * intermediate never leaves the chip.  float32.  x [B,H,W,Cin] (Cin % 32 == 0, >= 64); wt2 [64][9*Cin]
+ * (k order kh, kw, c); wt3 [Cout][64] (Cout % 128 == 0); res / y as in dvsg_conv_gemm_f32. */
+int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, const float *wt3, const float *bias3,
+                         const float *res, float *y, int B, int H, int W, int Cin, int Cout, int stride, int res_stride,
+                         void *stream);
+
+/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant", "fuse_conv").  Process-global. */
 int dvsg_debug_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------

@@ -156,6 +156,33 @@ def test_split_k_reduction_is_exact_and_deterministic():
         assert float((outs[1] - ref).abs().max()) <= 2e-5 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("B,h,w,cin,cout,stride,res_stride", [(2, 45, 80, 64, 256, 1, 1), (1, 37, 53, 64, 256, 2, 2),
+                                                             (3, 20, 31, 128, 128, 1, 1), (1, 90, 160, 64, 256, 2, 1)])
+def test_fused_conv3x3_conv1x1(B, h, w, cin, cout, stride, res_stride):
+    """Block 1's conv2 + conv3 in one kernel against two torch convolutions (float32): ragged M tiles,
+    stride 2 with the subsampled-shortcut residual, other channel counts."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
+    w2 = (torch.rand((64, 9 * cin), generator=g, device=dev) - 0.5) * (2.0 / (9 * cin) ** 0.5)
+    b2 = torch.rand((64,), generator=g, device=dev) - 0.5
+    w3 = (torch.rand((cout, 64), generator=g, device=dev) - 0.5) * 0.25
+    b3 = torch.rand((cout,), generator=g, device=dev) - 0.5
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = torch.rand((B, (ho - 1) * res_stride + 1, (wo - 1) * res_stride + 1, cout), generator=g, device=dev) - 0.5
+    y = torch.full((B, ho, wo, cout), float("nan"), device=dev)
+    _lib.call("dvsg_conv3x3_1x1_f32", x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(),
+              res.data_ptr(), y.data_ptr(), B, h, w, cin, cout, stride, res_stride, torch.cuda.current_stream().cuda_stream)
+    w2c = w2.reshape(64, 3, 3, cin).permute(0, 3, 1, 2)
+    mid = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w2c, b2, stride=stride, padding=1))
+    ref = torch.nn.functional.conv2d(mid, w3.reshape(cout, 64, 1, 1), b3).permute(0, 2, 3, 1)
+    ref = torch.relu(ref + res[:, ::res_stride, ::res_stride])
+    assert bool(torch.isfinite(y).all())
+    assert float((y - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 17, 23), (1, 40, 300), (33, 32, 32)])
 def test_ragged_and_extreme_shapes(net, synthetic_weights, B, H, W):
     """Tiny frames (every late feature map is 1x1), a width whose conv1 row needs a full and a

@@ -25,6 +25,8 @@ def short(n):
 
 def kclass(name):
     s = short(name)
+    if s.startswith("conv3x3_1x1_kernel"):   # block 1's fused conv2 + conv3: booked with the 3x3 class (ProfScope in conv_fused.hip)
+        return 1
     if s.startswith("conv_gemm"):
         m = re.match(r"conv_gemm_kernel<\w+, (\d+), (\d+), (\d+), (\d+)", s)   # <T, BN, WM, WN, KS, ...>
         return 1 if m and m.group(4) == "3" else 2
