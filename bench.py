@@ -34,8 +34,10 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
-KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*> + conv3x3_1x1_kernel", 2: "conv_gemm_kernel<*,1,*>",
-                  3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel"}
+MFMA_CLASSES = (0, 1, 2, 8)
+KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*>", 2: "conv_gemm_kernel<*,1,*>",
+                  3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel",
+                  8: "conv3x3_1x1_kernel"}
 
 
 def gpu_windows(B, H, W, seed, dev, S=7):
@@ -232,7 +234,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         total_ms, launches, flops, nbytes = prof
         cls = args.prof_class
-        if cls <= 2:
+        if cls in MFMA_CLASSES:
             achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
             peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" or cls == 0 else PEAK_F16_MFMA_TFLOPS
             roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
@@ -244,7 +246,7 @@ def main():
         roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel": KERNEL_CLASSES[cls], "launches": launches,
                          "avg_launch_ms": total_ms / max(launches, 1),
-                         "algorithmic_per_launch": (flops if cls <= 2 else nbytes) / max(launches, 1),
+                         "algorithmic_per_launch": (flops if cls in MFMA_CLASSES else nbytes) / max(launches, 1),
                          "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
         if (B, H, W) == (16, 720, 1280):
             which = "configs[1]"

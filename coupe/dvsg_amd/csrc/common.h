@@ -57,7 +57,8 @@ enum KernelClass {
   kClsTpsSolve = 5,
   kClsTpsWarp = 6,
   kClsStn = 7,     // flow / sampler B / affine / projective / elastic
-  kNumCls = 8
+  kClsFused = 8,   // conv3x3_1x1_kernel (block 1's conv2 + conv3)
+  kNumCls = 9
 };
 // RAII: when profiling is armed for `cls`, brackets the launches issued in its lifetime with a
 // hipEvent pair on `s` and books their algorithmic FLOPs / bytes.  Otherwise a no-op.

@@ -286,7 +286,7 @@ int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
   d.mtiles = (int)((M + BM - 1) / BM);
   const int res = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2;
   // algorithmic work: both contractions; bytes = input + both weight sets + residual + output, once each
-  ProfScope prof(kClsConv3x3, s, 2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID,
+  ProfScope prof(kClsFused, s, 2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID,
                  4.0 * ((double)p.B * p.H * p.W * p.Cin + (double)CMID * 9 * p.Cin + (double)p.Cout * CMID +
                         2.0 * (double)M * p.Cout));
   if (res == 1)

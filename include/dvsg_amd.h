@@ -238,7 +238,8 @@ int dvsg_debug_set_option(const char *name, int value);
  * by a hipEvent pair on the launch stream.  dvsg_prof_end synchronises on those events and
  * returns the summed durations, the launch count and the algorithmic FLOPs / bytes of those
  * launches.  Classes: 0 conv1 (7x7/2 + scale_RGB), 1 conv 3x3, 2 conv 1x1, 3 max pool,
- * 4 head (avg pool + dense), 5 TPS solve, 6 TPS grid + sampler A, 7 flow / STN samplers.
+ * 4 head (avg pool + dense), 5 TPS solve, 6 TPS grid + sampler A, 7 flow / STN samplers,
+ * 8 block 1's fused conv2 + conv3.
  * Process-global and not thread-safe: arm it only around single-threaded benchmark code.
  * ------------------------------------------------------------------------------------- */
 int dvsg_prof_begin(int kernel_class);

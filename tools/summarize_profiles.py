@@ -25,8 +25,8 @@ def short(n):
 
 def kclass(name):
     s = short(name)
-    if s.startswith("conv3x3_1x1_kernel"):   # block 1's fused conv2 + conv3: booked with the 3x3 class (ProfScope in conv_fused.hip)
-        return 1
+    if s.startswith("conv3x3_1x1_kernel"):   # block 1's fused conv2 + conv3
+        return 8
     if s.startswith("conv_gemm"):
         m = re.match(r"conv_gemm_kernel<\w+, (\d+), (\d+), (\d+), (\d+)", s)   # <T, BN, WM, WN, KS, ...>
         return 1 if m and m.group(4) == "3" else 2
@@ -74,7 +74,7 @@ def main(src, dst, tag):
     fetch, fdisp = write_pmc(src + "/pmc_fetch", "%s/%s_pmc_fetch.csv" % (dst, tag))
     write, wdisp = write_pmc(src + "/pmc_write", "%s/%s_pmc_write.csv" % (dst, tag))
     traffic = {}
-    for cls in range(8):
+    for cls in range(9):
         fb = sum(fetch[k]["FETCH_SIZE"] for k in fetch if kclass(k) == cls) * 1024.0 * 2.0
         fn = sum(len(fdisp[k]) for k in fetch if kclass(k) == cls)
         wb = sum(write[k]["WRITE_SIZE"] for k in write if kclass(k) == cls) * 1024.0
