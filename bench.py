@@ -118,15 +118,37 @@ def cpu_baseline(weights, H, W, budget_s=20.0):
                       "warm-up; median" % (len(times), W, H)}
 
 
+def cpu_baseline_flow(H, W, budget_s=10.0):
+    """CPU oracle of tf_warp (NumPy, one thread) on one frame at a time."""
+    from oracle.warp_with_optical_flow import tf_warp as o_tf_warp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import inputs
+    im = inputs.smooth_frames(1234, 1, H, W)
+    flow = inputs.smooth_flow(4321, 1, H, W)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start < budget_s or len(times) < 2):
+        t0 = time.perf_counter()
+        o_tf_warp(im, flow, H, W)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:] if len(times) > 2 else times))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d single-frame (%dx%d) passes of the NumPy tf_warp oracle; median" % (len(times), W, H)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--workload", default="stabilize", choices=["stabilize", "tf_warp"],
+                    help="stabilize: the headline path (CNN + TPS + sampler, configs[1]); tf_warp: the optical-flow "
+                         "warp alone (configs[2], batch 64)")
+    ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (stabilize) / 64 (tf_warp)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--prof-class", type=int, default=1, help="kernel class timed for the roofline object")
+    ap.add_argument("--prof-class", type=int, default=None,
+                    help="kernel class timed for the roofline object (default: 1 = 3x3 convs, or 7 for tf_warp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
@@ -160,11 +182,26 @@ def main():
     from coupe.dvsg_amd.networks import LocNet
     from coupe.dvsg_amd.weights import make_synthetic_weights
 
+    flow_mode = args.workload == "tf_warp"
+    if args.batch is None:
+        args.batch = 64 if flow_mode else 16
+    if args.prof_class is None:
+        args.prof_class = 7 if flow_mode else 1
     B, H, W = args.batch, args.height, args.width
-    weights = make_synthetic_weights(seed=0)
-    net = LocNet(weights)
-    patches = gpu_windows(B, H, W, 1234 + rank, dev)
-    u_t = patches[..., 18:].contiguous()
+    weights = net = patches = u_t = flow = None
+    if flow_mode:
+        # SURVEY.md 8d cfg 3: frames as cfg 2; flow ~ N(0, 4 px) smoothed by a 15-px box, 1 % of the pixels out of bounds
+        u_t = gpu_windows(B, H, W, 1234 + rank, dev, S=1)
+        g = torch.Generator(device=dev).manual_seed(4321 + rank)
+        flow = 4.0 * 15.0 * torch.randn((B, 2, H, W), generator=g, device=dev)
+        flow = F.avg_pool2d(flow, 15, stride=1, padding=7).permute(0, 2, 3, 1).contiguous()
+        oob = torch.rand((B, H, W, 1), generator=g, device=dev) < 0.01
+        flow = torch.where(oob, flow + (max(H, W) + 5.0), flow).contiguous()
+    else:
+        weights = make_synthetic_weights(seed=0)
+        net = LocNet(weights)
+        patches = gpu_windows(B, H, W, 1234 + rank, dev)
+        u_t = patches[..., 18:].contiguous()
     outs = [torch.empty((B, H, W, 3), device=dev) for _ in range(2)]
     F_t = torch.empty((B, 25, 2), device=dev)
     gather_bufs = None
@@ -182,7 +219,11 @@ def main():
             pending[slot].wait()
             pending[slot] = None
         out = outs[slot]
-        net.stabilize(patches, u_t, out, F_t, n_streams=args.streams, precision=args.precision)  # dvsg_stabilize_*
+        if flow_mode:
+            _lib.call("dvsg_flow_warp_f32", u_t.data_ptr(), flow.data_ptr(), B, H, W, 3, out.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+        else:
+            net.stabilize(patches, u_t, out, F_t, n_streams=args.streams, precision=args.precision)  # dvsg_stabilize_*
         if dist is not None and not args.no_gather:
             if on_host:   # rehearsal path: synchronous, through host memory
                 dist.gather(out.cpu(), gather_bufs[slot] if rank == 0 else None, dst=0)
@@ -248,7 +289,9 @@ def main():
                          "avg_launch_ms": total_ms / max(launches, 1),
                          "algorithmic_per_launch": (flops if cls in MFMA_CLASSES else nbytes) / max(launches, 1),
                          "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
-        if (B, H, W) == (16, 720, 1280):
+        if flow_mode:
+            which = "configs[2]" if (B, H, W) == (64, 720, 1280) else "non-BASELINE shape"
+        elif (B, H, W) == (16, 720, 1280):
             which = "configs[1]"
         elif (B, H, W, args.precision) == (32, 2160, 3840, "f16"):
             which = "configs[4]"
@@ -257,19 +300,21 @@ def main():
         else:
             which = "non-BASELINE shape"
         line = {
-            "metric": "stabilized frames/sec (%dx%d RGB)" % (W, H), "value": frames / elapsed, "unit": "frames/s",
+            "metric": ("tf_warp frames/sec (%dx%d RGB)" if flow_mode else "stabilized frames/sec (%dx%d RGB)") % (W, H),
+            "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if flow_mode else args.precision,
             "data": "synthetic",
-            "config": {"workload": "%s: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU"
-                                   % (which, B, W, H),
+            "config": {"workload": ("%s: batch=%d %dx%d frames, optical-flow warp (warp_with_optical_flow.tf_warp) per GPU"
+                                    if flow_mode else
+                                    "%s: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU") % (which, B, W, H),
                        "batch_per_gpu": B, "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
                        "gather": bool(dist is not None and not args.no_gather), "streams_per_gpu": args.streams,
-                       "weights": "synthetic seed 0 (reference ships no checkpoint)"},
+                       "weights": "n/a" if flow_mode else "synthetic seed 0 (reference ships no checkpoint)"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(weights, H, W)
+            line["cpu_baseline"] = cpu_baseline_flow(H, W) if flow_mode else cpu_baseline(weights, H, W)
         print(json.dumps(line), flush=True)
     if dist is not None:
         barrier()

@@ -40,3 +40,9 @@ def test_bench_other_kernel_classes_and_precision():
              "--no-cpu-baseline", "--precision", "f16")
     assert d["dtype"] == "f16" and d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s"
     assert "cpu_baseline" not in d
+
+
+def test_bench_tf_warp_workload():
+    d = _run("--workload", "tf_warp", "--steps", "2", "--warmup", "1", "--batch", "3", "--height", "96", "--width", "160")
+    assert d["metric"].startswith("tf_warp") and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
+    assert d["roofline"]["kernel"] == "stn_kernel" and d["roofline"]["launches"] == 2 and d["cpu_baseline"]["cores"] == 1
