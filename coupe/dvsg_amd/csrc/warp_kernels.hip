@@ -207,8 +207,25 @@ __device__ __forceinline__ void sample_a_blend(const TapsA<C> &t, int Cn, float 
 // [-1,H], +1 into the zero-ringed image, floor, upper index min()-ed, weights from the
 // UNclamped x0+1.  The ring is never materialised: a tap on it reads as 0.
 template <int C>
-__device__ __forceinline__ void sample_padded(const float *__restrict__ img, int H, int W, int Cn,
-                                              float x, float y, float *__restrict__ dst) {
+struct TapsB {  // loaded taps (x0,y0) (x1,y0) (x0,y1) (x1,y1), weights, and which taps are on the ring
+  Pix<C> a, b, c, d;
+  float w00, w01, w10, w11;
+  bool v00, v01, v10, v11;
+};
+template <>
+struct TapsB<0> {  // generic channel count: the blend reads through the tap pointers
+  const float *p00, *p01, *p10, *p11;
+  float w00, w01, w10, w11;
+  bool v00, v01, v10, v11;
+};
+
+// Address / weight computation and the four tap loads (only ISSUED here, so a thread can put the taps
+// of several pixels in flight before it blends the first one).  A tap on the ring reads as 0: the
+// loads are unconditional, from indices clamped into the image, and the ring is applied in the blend
+// as a select -- a predicated load that feeds arithmetic makes the compiler wait for each load in turn.
+template <int C>
+__device__ __forceinline__ void sample_padded_load(const float *__restrict__ img, int H, int W, int Cn, float x,
+                                                   float y, TapsB<C> &t) {
   const float wf = (float)W, hf = (float)H;
   x = fminf(fmaxf(x, -1.0f), wf);  // (W-1)+1
   y = fminf(fmaxf(y, -1.0f), hf);
@@ -219,39 +236,43 @@ __device__ __forceinline__ void sample_padded(const float *__restrict__ img, int
   const int x0 = (int)x0f, y0 = (int)y0f;
   const int x1 = (int)fminf(x1f, wf + 1.0f);
   const int y1 = (int)fminf(y1f, hf + 1.0f);
-  const float w00 = (x1f - x) * (y1f - y);
-  const float w01 = (x - x0f) * (y1f - y);
-  const float w10 = (x1f - x) * (y - y0f);
-  const float w11 = (x - x0f) * (y - y0f);
+  t.w00 = (x1f - x) * (y1f - y);
+  t.w01 = (x - x0f) * (y1f - y);
+  t.w10 = (x1f - x) * (y - y0f);
+  t.w11 = (x - x0f) * (y - y0f);
   const bool vx0 = x0 >= 1 && x0 <= W, vx1 = x1 >= 1 && x1 <= W;
   const bool vy0 = y0 >= 1 && y0 <= H, vy1 = y1 >= 1 && y1 <= H;
-  // A tap on the ring reads as 0.  The loads are unconditional, from indices clamped into the image,
-  // and the ring is applied afterwards as a select: a predicated load that feeds arithmetic makes
-  // the compiler wait for each load in turn instead of keeping all four in flight.
+  t.v00 = vx0 && vy0; t.v01 = vx1 && vy0; t.v10 = vx0 && vy1; t.v11 = vx1 && vy1;
   const int xa = clampi(x0 - 1, 0, W - 1), xb = clampi(x1 - 1, 0, W - 1);
   const int ya = clampi(y0 - 1, 0, H - 1), yb = clampi(y1 - 1, 0, H - 1);
   const float *p00 = img + ((long)ya * W + xa) * Cn;
   const float *p01 = img + ((long)ya * W + xb) * Cn;
   const float *p10 = img + ((long)yb * W + xa) * Cn;
   const float *p11 = img + ((long)yb * W + xb) * Cn;
-  if (C > 0) {
-    constexpr int CC = C > 0 ? C : 1;
-    const Pix<CC> a = load_pix<CC>(p00);
-    const Pix<CC> bq = load_pix<CC>(p01);
-    const Pix<CC> cq = load_pix<CC>(p10);
-    const Pix<CC> d = load_pix<CC>(p11);
-    const bool v00 = vx0 && vy0, v01 = vx1 && vy0, v10 = vx0 && vy1, v11 = vx1 && vy1;
+  if constexpr (C > 0) {
+    t.a = load_pix<C>(p00);
+    t.b = load_pix<C>(p01);
+    t.c = load_pix<C>(p10);
+    t.d = load_pix<C>(p11);
+  } else {
+    t.p00 = p00; t.p01 = p01; t.p10 = p10; t.p11 = p11;
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void sample_padded_blend(const TapsB<C> &t, int Cn, float *__restrict__ dst) {
+  if constexpr (C > 0) {
 #pragma unroll
     for (int c = 0; c < C; ++c)
-      dst[c] = ((w00 * (v00 ? a.v[c] : 0.f) + w01 * (v01 ? bq.v[c] : 0.f)) + w10 * (v10 ? cq.v[c] : 0.f)) +
-               w11 * (v11 ? d.v[c] : 0.f);
+      dst[c] = ((t.w00 * (t.v00 ? t.a.v[c] : 0.f) + t.w01 * (t.v01 ? t.b.v[c] : 0.f)) + t.w10 * (t.v10 ? t.c.v[c] : 0.f)) +
+               t.w11 * (t.v11 ? t.d.v[c] : 0.f);
   } else {
     for (int c = 0; c < Cn; ++c) {
-      const float a = (vx0 && vy0) ? p00[c] : 0.f;
-      const float bq = (vx1 && vy0) ? p01[c] : 0.f;
-      const float cq = (vx0 && vy1) ? p10[c] : 0.f;
-      const float d = (vx1 && vy1) ? p11[c] : 0.f;
-      dst[c] = ((w00 * a + w01 * bq) + w10 * cq) + w11 * d;
+      const float a = t.v00 ? t.p00[c] : 0.f;
+      const float bq = t.v01 ? t.p01[c] : 0.f;
+      const float cq = t.v10 ? t.p10[c] : 0.f;
+      const float d = t.v11 ? t.p11[c] : 0.f;
+      dst[c] = ((t.w00 * a + t.w01 * bq) + t.w10 * cq) + t.w11 * d;
     }
   }
 }
@@ -432,23 +453,39 @@ __global__ __launch_bounds__(kThreads) void stn_kernel(StnParams p) {
   if (j >= p.out_w) return;
   const float *img = p.im ? p.im + (size_t)b * p.H * p.W * p.Cn : nullptr;
   const float x_t = -1.0f + p.step_x * (float)j;
+  // Three passes over the thread's PPT rows so that memory operations of all rows are in flight
+  // together: coordinates (the flow / coordinate loads), then the 4 x PPT tap loads, then the blends.
+  float xx[PPT], yy[PPT];
+  float2 fl[PPT];
+  if (SRC == kFlow) {
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const int i = i0 + r < p.out_h ? i0 + r : p.out_h - 1;
+      fl[r] = reinterpret_cast<const float2 *>(p.a)[((size_t)b * p.out_h + i) * p.out_w + j];
+    }
+  } else if (SRC == kCoords) {
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+      const int i = i0 + r < p.out_h ? i0 + r : p.out_h - 1;
+      const size_t pix = ((size_t)b * p.out_h + i) * p.out_w + j;
+      fl[r] = make_float2(p.a[pix], p.b[pix]);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < PPT; ++r) {
     const int i = i0 + r;
-    if (i >= p.out_h) break;
     const size_t pix = ((size_t)b * p.out_h + i) * p.out_w + j;
     const float y_t = -1.0f + p.step_y * (float)i;
     float xs, ys, x, y;
     if (SRC == kFlow) {
-      const float2 f = reinterpret_cast<const float2 *>(p.a)[pix];
-      x = (float)j + f.x;  // :117-119
-      y = (float)i + f.y;
+      x = (float)j + fl[r].x;  // :117-119
+      y = (float)i + fl[r].y;
       xs = x;
       ys = y;
     } else {
       if (SRC == kCoords) {
-        xs = p.a[pix];
-        ys = p.b[pix];
+        xs = fl[r].x;
+        ys = fl[r].y;
       } else if (SRC == kAffine) {
         xs = (sth[0] * x_t + sth[1] * y_t) + sth[2];  // theta . [x_t; y_t; 1] in k order (:85)
         ys = (sth[3] * x_t + sth[4] * y_t) + sth[5];
@@ -474,15 +511,24 @@ __global__ __launch_bounds__(kThreads) void stn_kernel(StnParams p) {
       x = ((xs + 1.0f) / 2.0f) * ((float)p.W - 1.0f);
       y = ((ys + 1.0f) / 2.0f) * ((float)p.H - 1.0f);
     }
-    if (SRC != kFlow && SRC != kCoords) {
+    if (SRC != kFlow && SRC != kCoords && i < p.out_h) {
       if (p.xs_out) p.xs_out[pix] = xs;
       if (p.ys_out) p.ys_out[pix] = ys;
     }
-    if (img) {
-      float v[C > 0 ? C : kMaxGenericC];
-      sample_padded<C>(img, p.H, p.W, p.Cn, x, y, v);
-      store_pix<C>(p.out, pix, p.Cn, v);
-    }
+    xx[r] = x;
+    yy[r] = y;
+  }
+  if (!img) return;
+  TapsB<C> taps[PPT];
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) sample_padded_load<C>(img, p.H, p.W, p.Cn, xx[r], yy[r], taps[r]);
+#pragma unroll
+  for (int r = 0; r < PPT; ++r) {
+    const int i = i0 + r;
+    if (i >= p.out_h) break;
+    float v[C > 0 ? C : kMaxGenericC];
+    sample_padded_blend<C>(taps[r], p.Cn, v);
+    store_pix<C>(p.out, ((size_t)b * p.out_h + i) * p.out_w + j, p.Cn, v);
   }
 }
 
@@ -507,7 +553,7 @@ inline float lin_step(int n) { return n > 1 ? (1.0f - (-1.0f)) / (float)(n - 1) 
 
 template <int SRC>
 int launch_stn(StnParams p, int B, hipStream_t s, const char *what) {
-  constexpr int PPT = 2;
+  constexpr int PPT = (SRC == kFlow || SRC == kCoords) ? 4 : 2;  // memory-fed coordinates: more loads in flight per thread
   dim3 grid(ceil_div(p.out_w, kThreads), ceil_div(p.out_h, PPT), B);
   // algorithmic bytes per output pixel: read C + write C floats (+ flow 8 B / coords 8 B)
   const double px = (double)B * p.out_h * p.out_w;
