@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
                     help="f32 (default, the reference's arithmetic: the headline number) or f16 activations/weights")
     ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the batch of one step is split over (LocNet.stabilize); 2 is ~4 %% faster "
+                    help="HIP streams the batch of one step is split over (LocNet.stabilize); 2 is <1 %% faster "
                          "but concurrent launches make the per-kernel hipEvent durations of `roofline` meaningless")
     args = ap.parse_args()
 

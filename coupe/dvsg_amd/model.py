@@ -62,7 +62,7 @@ class StabNet:
         self.num_control_points = 5
         self.param_dim = self.num_control_points ** 2
         self.stabNet_model = 'resnet_v1_50'
-        self.n_streams = 1   # 2 = batch halves on two HIP streams (LocNet.stabilize): +4 % at B=16 720p
+        self.n_streams = 1   # 2 = batch halves on two HIP streams (LocNet.stabilize): <1 % at B=16 720p
         self.precision = "f32"   # "f16": float16 activations / conv weights in localizationNet
         self.locnet = None
         self.inputs = None
