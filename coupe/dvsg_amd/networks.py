@@ -81,8 +81,9 @@ class LocNet(object):
         """`dvsg_stabilize_f32` on device tensors, optionally with the batch split over
         `n_streams` side streams: every conv launch covers the chip in a few rounds of tiles and
         its last round is only partly full; launches from two independent half batches fill each
-        other's tails (+4 % at B=16 720p before the stream-K tail, <1 % since).  Results do not depend on the split (samples are
-        independent); the caller's stream sees one fork / join."""
+        other's tails (+4 % at B=16 720p before the stream-K tail, <1 % since).  Results do not
+        depend on the split beyond float32 re-association (samples are independent); the
+        caller's stream sees one fork / join."""
         import torch
         fn = _entry("dvsg_stabilize", precision)
         B, H, W, _ = u_t.shape
