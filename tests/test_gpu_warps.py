@@ -81,6 +81,36 @@ def test_tps_warp_given_T(dev, B, H, W, C):
     assert mask.mean() < 0.05
 
 
+def test_tps_warp_white_noise_stress(dev):
+    """SURVEY.md section 7, hard part 2: the stress case reported separately.  On white-noise frames the
+    image gradient is up to 1 per pixel, so a warped pixel may differ by the full source-coordinate
+    error (in pixels, both axes) -- and by no more than that."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    B, H, W, C = 2, 72, 128, 3
+    U = np.random.default_rng(31).uniform(0.0, 1.0, (B, H, W, C)).astype(np.float32)
+    coord = inputs.v_src(B)
+    T = otps.solve_system(coord, (coord + inputs.control_vectors(32, B)).astype(np.float32))
+    xo, yo = otps.source_coords(T, coord, H, W)
+    ref = otps.interpolate_a(U, xo, yo).reshape(B, H, W, C)
+    tU, tc, tT = (torch.from_numpy(a).to(dev) for a in (U, coord, T))
+    out = torch.empty((B, H, W, C), device=dev)
+    xs = torch.empty((B * H * W,), device=dev)
+    ys = torch.empty((B * H * W,), device=dev)
+    _lib.call("dvsg_tps_warp_f32", tU.data_ptr(), tc.data_ptr(), tT.data_ptr(), B, H, W, C, 25, H, W,
+              out.data_ptr(), xs.data_ptr(), ys.data_ptr(), 0)
+    torch.cuda.synchronize()
+    xs, ys = xs.cpu().numpy().reshape(B, -1), ys.cpu().numpy().reshape(B, -1)
+    ex = np.abs(xs - xo).reshape(B, H, W) * W / 2
+    ey = np.abs(ys - yo).reshape(B, H, W) * H / 2
+    mask = otps.border_discontinuity_mask(xo, yo, H, W).reshape(B, H, W)
+    err = np.abs(out.cpu().numpy() - ref).max(axis=3)
+    # slack: the pixel coordinate (x + 1) * W / 2 itself carries half an ulp of W (4e-6 px at W = 128)
+    slack = err - 2.0 * (ex + ey)
+    assert slack[~mask].max() <= 2e-5, "worst excess %.3g (grid error there %.3g px)" % (slack[~mask].max(), (ex + ey)[~mask][np.argmax(slack[~mask])])
+    assert err[~mask].max() < 5e-3
+
+
 @pytest.mark.parametrize("out_size", [(72, 128), (36, 64), (50, 90)])
 def test_thin_plate_spline_facade(dev, out_size):
     """Whole operator (solve + grid + sampler A), reference signature and return order."""
