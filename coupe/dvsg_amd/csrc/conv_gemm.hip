@@ -335,6 +335,22 @@ void conv_gemm_kernel(ConvGemmDev p) {
       }
       __syncthreads();
     }
+    // The finisher sums the partial tiles contributor by contributor (K order), all of the thread's
+    // rows per step: NROW independent loads in flight instead of one (the row-by-row form made a
+    // batch-1 split-K launch wait for NROW x n_contrib L2 round trips in sequence).
+    floatx4 vsum[NROW];  // (an ext-vector type: arrays of the float4 struct spill)
+    if (reduce) {
+#pragma unroll
+      for (int i = 0; i < NROW; ++i) vsum[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < n_contrib; ++j) {
+        const float *src = j == own ? Cs + 4 * col4 : slab_of(j) + 4 * col4;
+        const int ld = j == own ? LDC : BN;
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) {
+          vsum[i] += *reinterpret_cast<const floatx4 *>(src + (row0 + i * RSTEP) * ld);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NROW; ++i) {
       const int row = row0 + i * RSTEP;
@@ -342,12 +358,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       if (m >= p.M) break;
       float4 v;
       if (reduce) {
-        v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = 0; j < n_contrib; ++j) {
-          const float4 t = j == own ? *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4)
-                                    : *reinterpret_cast<const float4 *>(slab_of(j) + row * BN + 4 * col4);
-          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
+        v = make_float4(vsum[i][0], vsum[i][1], vsum[i][2], vsum[i][3]);
       } else {
         v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
       }
