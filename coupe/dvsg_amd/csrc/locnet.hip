@@ -61,6 +61,7 @@ struct dvsg_locnet {
   float *dense_w[4] = {nullptr, nullptr, nullptr, nullptr};
   float *dense_b[4] = {nullptr, nullptr, nullptr, nullptr};
   float *v_src = nullptr;  // [25,2] model.py:105-110
+  double *winv = nullptr;  // [25][28]: columns of the TPS system's inverse for v_src (see tps_apply_kernel)
   std::vector<void *> allocs;
 };
 
@@ -349,7 +350,7 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
                        as_stream(stream)))
     return rc;
   // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111); float32
-  if (int rc = tps_solve_impl(net->v_src, 0, F, 1, B, 25, ws.T, stream)) return rc;
+  if (int rc = tps_apply_impl(net->winv, net->v_src, F, 1, B, 25, ws.T, stream)) return rc;
   return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
 }
 
@@ -455,6 +456,16 @@ int dvsg_locnet_create(int n_arrays, const char *const *names, const float *cons
       vs[(i * 5 + j) * 2 + 1] = -1.0f + 0.5f * i;
     }
   if ((rc = upload(net, vs, &net->v_src))) return bail(rc);
+  {  // the TPS system of the constant V_src grid is inverted once (float64)
+    void *w = nullptr, *scratch = nullptr;
+    if (hipMalloc(&w, 25 * 28 * sizeof(double)) != hipSuccess) return bail(fail(DVSG_ERR_HIP, "hipMalloc failed"));
+    net->allocs.push_back(w);
+    if (hipMalloc(&scratch, 13 * 25 * 2 * sizeof(float)) != hipSuccess) return bail(fail(DVSG_ERR_HIP, "hipMalloc failed"));
+    rc = tps_inverse_columns(net->v_src, 25, static_cast<double *>(w), static_cast<float *>(scratch), nullptr);
+    (void)hipFree(scratch);
+    if (rc) return bail(rc);
+    net->winv = static_cast<double *>(w);
+  }
   *out = net;
   return DVSG_OK;
 }

@@ -12,6 +12,8 @@
 // This translation unit is compiled with -ffp-contract=off: the reference graph is a chain
 // of separately rounded float32 mul / add ops, and keeping the same roundings lets the
 // parity tests compare source coordinates to the oracle within 1-2 ulp (only logf differs).
+#include <vector>
+
 #include "common.h"
 
 namespace dvsg {
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__
                                                        long coord_bstride,
                                                        const float *__restrict__ rhs,
                                                        int rhs_is_vector, int P,
-                                                       float *__restrict__ T) {
+                                                       float *__restrict__ T, double *__restrict__ Td) {
   __shared__ double A[64 * kSolveLd];
   __shared__ float cx[64], cy[64];
   __shared__ int pivrow[64];
@@ -115,8 +117,47 @@ __global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__
   if (t < n) {
     const double *prow = A + pivrow[t] * kSolveLd;
     const double piv = prow[t];
-    T[((size_t)b * 2 + 0) * n + t] = (float)(prow[n] / piv);
-    T[((size_t)b * 2 + 1) * n + t] = (float)(prow[n + 1] / piv);
+    if (Td) {  // float64 solution (columns of W^-1 for tps_apply_kernel)
+      Td[((size_t)b * 2 + 0) * n + t] = prow[n] / piv;
+      Td[((size_t)b * 2 + 1) * n + t] = prow[n + 1] / piv;
+    } else {
+      T[((size_t)b * 2 + 0) * n + t] = (float)(prow[n] / piv);
+      T[((size_t)b * 2 + 1) * n + t] = (float)(prow[n + 1] / piv);
+    }
+  }
+}
+
+// The evaluation graph solves the SAME 28x28 system for every frame: its control points are the
+// constant V_src grid (model.py:105-111), only the right-hand side (V_src + F_t) changes.  With the
+// first P columns of W^-1 computed once (float64, by the solver above on unit right-hand sides; the
+// last three right-hand-side rows are always zero), T = (W^-1 [coord + vector; 0])^T is 56 dot products
+// of length P per sample.  winv_cols is [P][n]: column j of W^-1.
+__global__ __launch_bounds__(64) void tps_apply_kernel(const double *__restrict__ winv_cols,
+                                                       const float *__restrict__ coord,
+                                                       const float *__restrict__ rhs, int rhs_is_vector,
+                                                       int P, float *__restrict__ T) {
+  __shared__ double yx[64], yy[64];
+  const int b = blockIdx.x, t = threadIdx.x, n = P + 3;
+  if (t < P) {
+    float rx = rhs[((size_t)b * P + t) * 2 + 0];
+    float ry = rhs[((size_t)b * P + t) * 2 + 1];
+    if (rhs_is_vector) {  // coord + vector in float32 (:161)
+      rx = coord[t * 2 + 0] + rx;
+      ry = coord[t * 2 + 1] + ry;
+    }
+    yx[t] = (double)rx;
+    yy[t] = (double)ry;
+  }
+  __syncthreads();
+  if (t < n) {
+    double ax = 0.0, ay = 0.0;
+    for (int j = 0; j < P; ++j) {
+      const double w = winv_cols[(size_t)j * n + t];
+      ax += w * yx[j];
+      ay += w * yy[j];
+    }
+    T[((size_t)b * 2 + 0) * n + t] = (float)ax;
+    T[((size_t)b * 2 + 1) * n + t] = (float)ay;
   }
 }
 
@@ -589,8 +630,39 @@ int tps_solve_impl(const float *coord, long coord_bstride, const float *rhs, int
   DVSG_REQUIRE(P >= 3 && P <= kMaxPts, "dvsg_tps_solve_f32: P=%d outside [3,%d]", P, kMaxPts);
   ProfScope prof(kClsTpsSolve, as_stream(stream), 0.0, (double)B * (4.0 * P + 2.0 * (P + 3)) * 4.0);
   hipLaunchKernelGGL(tps_solve_kernel, dim3(B), dim3(64), 0, as_stream(stream), coord, coord_bstride, rhs,
-                     rhs_is_vector, P, T);
+                     rhs_is_vector, P, T, static_cast<double *>(nullptr));
   return check_launch("tps_solve_kernel");
+}
+
+// Columns 0..P-1 of W^-1 for ONE set of control points, float64, winv_cols [P][P+3]; `scratch` holds
+// ceil(P/2) x P x 2 floats of unit right-hand sides.  Synchronous helper for handle creation.
+int tps_inverse_columns(const float *coord, int P, double *winv_cols, float *scratch, void *stream) {
+  DVSG_REQUIRE(coord && winv_cols && scratch, "tps_inverse_columns: NULL pointer");
+  DVSG_REQUIRE(P >= 3 && P <= kMaxPts, "tps_inverse_columns: P=%d outside [3,%d]", P, kMaxPts);
+  const int pairs = (P + 1) / 2, n = P + 3;
+  std::vector<float> eye((size_t)pairs * P * 2, 0.f);
+  for (int j = 0; j < P; ++j) eye[((size_t)(j / 2) * P + j) * 2 + (j % 2)] = 1.f;  // sample j/2, rhs column j%2: e_j
+  DVSG_HIP(hipMemcpyAsync(scratch, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, as_stream(stream)));
+  // sample b solves for columns 2b and 2b+1: Td[b][c][k] = (W^-1 e_{2b+c})[k], i.e. winv_cols[2b+c][k] -- contiguous
+  double *dtmp = nullptr;
+  DVSG_HIP(hipMalloc(&dtmp, (size_t)pairs * 2 * n * sizeof(double)));
+  hipLaunchKernelGGL(tps_solve_kernel, dim3(pairs), dim3(64), 0, as_stream(stream), coord, 0L, scratch, 0, P,
+                     static_cast<float *>(nullptr), dtmp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(winv_cols, dtmp, (size_t)P * n * sizeof(double), hipMemcpyDeviceToDevice, as_stream(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+  (void)hipFree(dtmp);
+  if (e != hipSuccess) return fail(DVSG_ERR_HIP, "tps_inverse_columns: %s", hipGetErrorString(e));
+  return DVSG_OK;
+}
+
+int tps_apply_impl(const double *winv_cols, const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
+                   float *T, void *stream) {
+  DVSG_REQUIRE(winv_cols && coord && rhs && T, "tps_apply: NULL pointer");
+  DVSG_REQUIRE(B > 0 && P >= 3 && P <= kMaxPts, "tps_apply: bad shape B=%d P=%d", B, P);
+  ProfScope prof(kClsTpsSolve, as_stream(stream), 0.0, (double)B * (4.0 * P + 2.0 * (P + 3)) * 4.0);
+  hipLaunchKernelGGL(tps_apply_kernel, dim3(B), dim3(64), 0, as_stream(stream), winv_cols, coord, rhs, rhs_is_vector, P, T);
+  return check_launch("tps_apply_kernel");
 }
 
 int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const float *T, int B, int H,
