@@ -1,5 +1,9 @@
-import os, sys, time, torch
-ROOT='/root/repo'; sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+'/tests')
+#!/usr/bin/env python3
+"""33 back-to-back batch-1 dvsg_stabilize calls at a given size, for rocprofv3 --kernel-trace --stats
+(which kernels make up a frame of the latency path).  Usage: tools/b1_profile.py H W"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from coupe.dvsg_amd.model import StabNet
 from coupe.dvsg_amd.weights import make_synthetic_weights
 H, W = int(sys.argv[1]), int(sys.argv[2])
