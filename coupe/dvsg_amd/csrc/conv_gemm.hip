@@ -47,9 +47,10 @@
 //   0  one workgroup per output tile.
 //   1  split-K: a launch with too few tiles for the chip (batch 1-2) gives each tile to `ksplit`
 //      workgroups, each running a contiguous slice of the K stages.
-//   2  stream-K tail: the tiles of the last, partly filled round of a large launch are cut into
-//      one equal share of (tile, K-stage) units per resident workgroup, so the round costs its
-//      share of the work instead of a full tile time.
+//   2  stream-K tail: blocks [0, tile_begin) run the tiles of the full rounds as in mode 0; in the
+//      SAME launch 512 more blocks share the tiles of the last, partly filled round (or a whole
+//      launch of 256-511 tiles) as equal runs of (tile, K-stage) units, so that round costs its share
+//      of the work instead of a full tile time.
 // Modes 1 and 2 reduce in the launch, last-arriver form: a contributor publishes its raw partial
 // tile, takes a ticket, and whoever draws the last ticket of a tile sums all partials in K order
 // (bitwise reproducible) and runs the epilogue.  No workgroup ever waits for another one.
