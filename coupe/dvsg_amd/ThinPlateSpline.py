@@ -5,8 +5,23 @@ Same call surface as ThinPlateSpline.py:4 (`ThinPlateSpline(U, coord, vector, ou
 target, out_size)`), taking / returning torch tensors on the HIP device (NumPy in ->
 NumPy out).  Compute: `dvsg_tps_solve_f32` + `dvsg_tps_warp_f32` (include/dvsg_amd.h).
 """
+import torch
+
 from . import _lib
 from ._tensor import as_dev, empty, like_input, ptr, stream
+
+
+def _solve(ct, rt, rhs_is_vector, B, P, T):
+    """`_solve_system` with tf.matrix_inverse's error behaviour (ThinPlateSpline.py:159): repeated or
+    collinear control points raise instead of warping with a garbage map.  Reading the 4-byte
+    flag back synchronises, as a sess.run of these ops would; the fused evaluation path
+    (`dvsg_stabilize_*`) inverts its constant V_src system once at load time and never comes here."""
+    flag = torch.zeros(1, dtype=torch.int32, device=ct.device)
+    _lib.call("dvsg_tps_solve_checked_f32", ptr(ct), ptr(rt), int(rhs_is_vector), B, P, ptr(T), ptr(flag), stream())
+    bad = int(flag.item())
+    if bad:
+        raise _lib.DvsgError("ThinPlateSpline: the control-point system of %d of %d samples is not invertible "
+                             "(repeated or collinear control points)" % (bad, B))
 
 
 def _tps(U, coord, rhs, out_size, rhs_is_vector):
@@ -25,7 +40,7 @@ def _tps(U, coord, rhs, out_size, rhs_is_vector):
     xs = empty((B * out_h * out_w,), Ut)
     ys = empty((B * out_h * out_w,), Ut)
     s = stream()
-    _lib.call("dvsg_tps_solve_f32", ptr(ct), ptr(rt), int(rhs_is_vector), B, P, ptr(T), s)
+    _solve(ct, rt, rhs_is_vector, B, P, T)
     _lib.call("dvsg_tps_warp_f32", ptr(Ut), ptr(ct), ptr(T), B, H, W, C, P, out_h, out_w,
               ptr(out), ptr(xs), ptr(ys), s)
     return like_input(out, U), like_input(xs, U), like_input(ys, U)
@@ -47,5 +62,5 @@ def solve_system(coord, rhs, rhs_is_vector=True):
     rt = as_dev(rhs)
     B, P, _ = ct.shape
     T = empty((B, 2, P + 3), ct)
-    _lib.call("dvsg_tps_solve_f32", ptr(ct), ptr(rt), int(rhs_is_vector), B, P, ptr(T), stream())
+    _solve(ct, rt, rhs_is_vector, B, P, T)
     return like_input(T, coord)

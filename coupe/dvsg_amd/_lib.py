@@ -19,6 +19,7 @@ _i = ctypes.c_int
 # name -> argtypes; every function returns int status except the three string/version queries.
 SIGNATURES = {
     "dvsg_tps_solve_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "dvsg_tps_solve_checked_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "dvsg_tps_warp_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dvsg_flow_warp_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dvsg_stn_sample_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
@@ -82,9 +83,10 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     _lib = lib
-    # diagnostic A/B switches for kernel experiments (see dvsg_debug_set_option in the header)
+    # diagnostic A/B switches for kernel experiments (see dvsg_debug_set_option in the header): they
+    # change which kernels production calls select, so they only apply under an explicit DVSG_DEBUG=1
     for env, opt in (("DVSG_CONV_VARIANT", b"conv_variant"), ("DVSG_FUSE_CONV", b"fuse_conv")):
-        if os.environ.get(env):
+        if os.environ.get(env) and os.environ.get("DVSG_DEBUG") == "1":
             check(lib.dvsg_debug_set_option(opt, int(os.environ[env])), "dvsg_debug_set_option")
     return lib
 

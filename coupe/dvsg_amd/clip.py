@@ -94,6 +94,13 @@ def window_index_table(n_frames, skip_length=SKIP_LENGTH):
     return table.astype(np.int32)
 
 
+def _check_window(model, S):
+    """A window of S frames is 3 S channels; conv1 of the loaded checkpoint fixes that number."""
+    if 3 * S != model.locnet.in_channels:
+        raise ValueError("skip_length has %d entries (%d channels) but conv1 of the loaded checkpoint has %d "
+                         "input channels" % (S, 3 * S, model.locnet.in_channels))
+
+
 def stabilize_clip(model, session, frames, skip_length=SKIP_LENGTH, side_by_side=False, channel_order="rgb",
                    as_uint8=False):
     """eval.py:76-124 for one clip, entirely on the device.
@@ -131,6 +138,7 @@ def stabilize_clip(model, session, frames, skip_length=SKIP_LENGTH, side_by_side
         raise ValueError("frames must be [N,h,w,3]")
     N, h, w = int(fr.shape[0]), model.h, model.w
     S = len(skip_length)
+    _check_window(model, S)
     table = torch.from_numpy(window_index_table(N, skip_length)).to(dev)
     pool = torch.empty((2 * N, h, w, 3), dtype=torch.float32, device=dev)
     fr = fr.to(dev).contiguous()
@@ -239,6 +247,7 @@ def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length
     if un.dim() != 4 or un.shape[3] != 3 or st.shape != un.shape:
         raise ValueError("unstable and stable clips must both be [N,h,w,3]")
     N, h, w, S = int(un.shape[0]), model.h, model.w, len(skip_length)
+    _check_window(model, S)
     span = int(skip_length[-1])
     table = torch.from_numpy(teacher_forced_index_table(N, skip_length)).to(dev)
     pool = torch.empty((2 * N, h, w, 3), dtype=torch.float32, device=dev)

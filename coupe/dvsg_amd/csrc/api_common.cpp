@@ -25,24 +25,37 @@ const char *dvsg_target_arch(void) { return "gfx950"; }
 }
 
 // ---- per-kernel-class timing -------------------------------------------------------------
+#include <atomic>
+#include <mutex>
 #include <vector>
 namespace dvsg {
 namespace {
+// The library may be called from several host threads (the error buffer is thread_local): the armed
+// class is an atomic, so the disarmed path costs one relaxed load, and the event lists are only
+// touched under the mutex.
 struct Prof {
-  int cls = -1;
+  std::atomic<int> cls{-1};
+  std::mutex mu;
   std::vector<hipEvent_t> start, stop;
   double flops = 0, bytes = 0;
 } g_prof;
 }  // namespace
 
 ProfScope::ProfScope(int cls, hipStream_t s, double flops, double bytes) : idx_(-1), s_(s) {
-  if (cls != g_prof.cls) return;
+  if (cls != g_prof.cls.load(std::memory_order_relaxed)) return;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess) return;
   if (hipEventCreate(&b) != hipSuccess) {
     (void)hipEventDestroy(a);
     return;
   }
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  if (cls != g_prof.cls.load(std::memory_order_relaxed)) {  // disarmed meanwhile
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return;
+  }
+  stop_ = b;
   g_prof.start.push_back(a);
   g_prof.stop.push_back(b);
   g_prof.flops += flops;
@@ -51,7 +64,7 @@ ProfScope::ProfScope(int cls, hipStream_t s, double flops, double bytes) : idx_(
   (void)hipEventRecord(a, s);
 }
 ProfScope::~ProfScope() {
-  if (idx_ >= 0) (void)hipEventRecord(g_prof.stop[idx_], s_);
+  if (idx_ >= 0) (void)hipEventRecord(stop_, s_);
 }
 }  // namespace dvsg
 
@@ -59,15 +72,18 @@ extern "C" {
 int dvsg_prof_begin(int kernel_class) {
   DVSG_REQUIRE(kernel_class >= 0 && kernel_class < dvsg::kNumCls, "dvsg_prof_begin: class %d outside [0,%d)",
                kernel_class, dvsg::kNumCls);
-  DVSG_REQUIRE(dvsg::g_prof.cls < 0, "dvsg_prof_begin: profiling already armed");
-  dvsg::g_prof.cls = kernel_class;
+  std::lock_guard<std::mutex> lock(dvsg::g_prof.mu);
+  DVSG_REQUIRE(dvsg::g_prof.cls.load() < 0, "dvsg_prof_begin: profiling already armed");
   dvsg::g_prof.flops = dvsg::g_prof.bytes = 0;
+  dvsg::g_prof.cls.store(kernel_class);
   return DVSG_OK;
 }
 
 int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes) {
   using dvsg::g_prof;
-  DVSG_REQUIRE(g_prof.cls >= 0, "dvsg_prof_end: profiling not armed");
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  DVSG_REQUIRE(g_prof.cls.load() >= 0, "dvsg_prof_end: profiling not armed");
+  g_prof.cls.store(-1);   // launches racing with this call stop recording
   double ms = 0;
   int rc = DVSG_OK;
   for (size_t i = 0; i < g_prof.start.size(); ++i) {
@@ -85,7 +101,6 @@ int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes)
   if (bytes) *bytes = g_prof.bytes;
   g_prof.start.clear();
   g_prof.stop.clear();
-  g_prof.cls = -1;
   return rc;
 }
 }

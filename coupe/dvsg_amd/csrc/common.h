@@ -37,7 +37,7 @@ inline int check_launch(const char *what) {
 
 // warp_kernels.hip internals shared with locnet.hip (coord_bstride in floats; 0 = broadcast)
 int tps_solve_impl(const float *coord, long coord_bstride, const float *rhs, int rhs_is_vector, int B,
-                   int P, float *T, void *stream);
+                   int P, float *T, int *n_singular, void *stream);
 // constant control points (the evaluation graph's V_src): W^-1 once, then a matrix-vector product per frame
 int tps_inverse_columns(const float *coord, int P, double *winv_cols, float *scratch, void *stream);
 int tps_apply_impl(const double *winv_cols, const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
@@ -71,5 +71,6 @@ struct ProfScope {
   ~ProfScope();
   int idx_;
   hipStream_t s_;
+  hipEvent_t stop_ = nullptr;
 };
 }  // namespace dvsg

@@ -193,8 +193,24 @@ constexpr int kMaxConvLaunches = 64;
 // Sized for float32 activations; the float16 run uses the same plan with half the bytes.
 Workspace plan(char *base, int B, int H, int W) {
   const Dims d = root_dims(H, W);
-  const size_t big = align256((size_t)B * d.Hp * d.Wp * 256 * sizeof(float));
-  const size_t small = align256((size_t)B * d.Hp * d.Wp * 64 * sizeof(float));
+  // Walk the 16 units with forward()'s own (h, w) recurrence: with the ceil in (h - 1) / stride + 1
+  // the per-sample element count does NOT shrink monotonically on tiny frames (8x8: block 4 needs
+  // 1x1x2048 > 2x2x256), so the buffers are sized by the largest tenant, not by the first one.
+  size_t big_el = std::max((size_t)d.H1 * d.W1 * 64, (size_t)d.Hp * d.Wp * 64);  // conv1 out (bufA), pool1 out (bufB)
+  size_t small_el = 0;
+  {
+    int h = d.Hp, w = d.Wp;
+    for (const BlockSpec &bs : kBlocks)
+      for (int u = 1; u <= bs.units; ++u) {
+        const int stride = u == bs.units ? bs.last_stride : 1;
+        const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+        small_el = std::max(small_el, (size_t)h * w * bs.base);                  // r1 (conv1 out), r2 <= r1
+        big_el = std::max(big_el, (size_t)ho * wo * bs.base * 4);                // unit out, shortcut
+        h = ho; w = wo;
+      }
+  }
+  const size_t big = align256((size_t)B * big_el * sizeof(float));
+  const size_t small = align256((size_t)B * small_el * sizeof(float));
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) {

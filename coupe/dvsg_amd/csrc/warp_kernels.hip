@@ -46,7 +46,8 @@ __global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__
                                                        long coord_bstride,
                                                        const float *__restrict__ rhs,
                                                        int rhs_is_vector, int P,
-                                                       float *__restrict__ T, double *__restrict__ Td) {
+                                                       float *__restrict__ T, double *__restrict__ Td,
+                                                       int *__restrict__ n_singular) {
   __shared__ double A[64 * kSolveLd];
   __shared__ float cx[64], cy[64];
   __shared__ int pivrow[64];
@@ -88,6 +89,12 @@ __global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__
     row[n + 1] = 0.0;
   }
   __syncthreads();
+  // scale of the system, for the singularity test below (the p columns hold 1.0, so amax >= 1)
+  double amax = 0.0;
+  if (t < n)
+    for (int c = 0; c < n; ++c) amax = fmax(amax, fabs(row[c]));
+  for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
+  double minpiv = amax;
   bool used = false;
   for (int k = 0; k < n; ++k) {
     double v = (t < n && !used) ? fabs(row[k]) : -1.0;
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__
     const int p = idx;
     const double *prow = A + p * kSolveLd;
     const double piv = prow[k];
+    minpiv = fmin(minpiv, fabs(piv));
     if (t < n && t != p) {
       const double f = row[k] / piv;
       for (int c = k; c < n + 2; ++c) row[c] -= f * prow[c];
@@ -113,11 +121,26 @@ __global__ __launch_bounds__(64) void tps_solve_kernel(const float *__restrict__
     }
     __syncthreads();
   }
+  // tf.matrix_inverse (:159) raises InvalidArgument ("Input is not invertible") when the LU has a
+  // zero pivot: repeated or collinear control points.  A launch cannot raise, so such a sample gets
+  // T = NaN (never a finite garbage map) and is counted in *n_singular for the host to turn into an
+  // error (dvsg_tps_solve_checked_f32).  Well-posed systems (cond(W) ~ 4e2) are nowhere near the bound.
+  const bool singular = !(minpiv > 1e-13 * amax);
+  if (singular && t == 0 && n_singular) atomicAdd(n_singular, 1);
   // T = (W^-1 tp)^T (:163-164): T[b][c][k]
   if (t < n) {
     const double *prow = A + pivrow[t] * kSolveLd;
-    const double piv = prow[t];
-    if (Td) {  // float64 solution (columns of W^-1 for tps_apply_kernel)
+    const double piv = singular ? 0.0 : prow[t];
+    if (singular) {
+      const double qnan = __builtin_nan("");
+      if (Td) {
+        Td[((size_t)b * 2 + 0) * n + t] = qnan;
+        Td[((size_t)b * 2 + 1) * n + t] = qnan;
+      } else {
+        T[((size_t)b * 2 + 0) * n + t] = (float)qnan;
+        T[((size_t)b * 2 + 1) * n + t] = (float)qnan;
+      }
+    } else if (Td) {  // float64 solution (columns of W^-1 for tps_apply_kernel)
       Td[((size_t)b * 2 + 0) * n + t] = prow[n] / piv;
       Td[((size_t)b * 2 + 1) * n + t] = prow[n + 1] / piv;
     } else {
@@ -624,13 +647,13 @@ int check_image_args(const char *fn, int B, int H, int W, int C, int out_h, int 
 // coord_bstride = 0 broadcasts one set of control points over the batch (model.py:111 tiles
 // the constant V_src; the fused evaluation graph does not materialise the tile).
 int tps_solve_impl(const float *coord, long coord_bstride, const float *rhs, int rhs_is_vector, int B,
-                   int P, float *T, void *stream) {
+                   int P, float *T, int *n_singular, void *stream) {
   DVSG_REQUIRE(coord && rhs && T, "dvsg_tps_solve_f32: NULL pointer");
   DVSG_REQUIRE(B > 0, "dvsg_tps_solve_f32: B=%d must be positive", B);
   DVSG_REQUIRE(P >= 3 && P <= kMaxPts, "dvsg_tps_solve_f32: P=%d outside [3,%d]", P, kMaxPts);
   ProfScope prof(kClsTpsSolve, as_stream(stream), 0.0, (double)B * (4.0 * P + 2.0 * (P + 3)) * 4.0);
   hipLaunchKernelGGL(tps_solve_kernel, dim3(B), dim3(64), 0, as_stream(stream), coord, coord_bstride, rhs,
-                     rhs_is_vector, P, T, static_cast<double *>(nullptr));
+                     rhs_is_vector, P, T, static_cast<double *>(nullptr), n_singular);
   return check_launch("tps_solve_kernel");
 }
 
@@ -644,15 +667,23 @@ int tps_inverse_columns(const float *coord, int P, double *winv_cols, float *scr
   for (int j = 0; j < P; ++j) eye[((size_t)(j / 2) * P + j) * 2 + (j % 2)] = 1.f;  // sample j/2, rhs column j%2: e_j
   DVSG_HIP(hipMemcpyAsync(scratch, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, as_stream(stream)));
   // sample b solves for columns 2b and 2b+1: Td[b][c][k] = (W^-1 e_{2b+c})[k], i.e. winv_cols[2b+c][k] -- contiguous
-  double *dtmp = nullptr;
-  DVSG_HIP(hipMalloc(&dtmp, (size_t)pairs * 2 * n * sizeof(double)));
-  hipLaunchKernelGGL(tps_solve_kernel, dim3(pairs), dim3(64), 0, as_stream(stream), coord, 0L, scratch, 0, P,
-                     static_cast<float *>(nullptr), dtmp);
-  hipError_t e = hipGetLastError();
+  double *dtmp = nullptr;   // [pairs][2][n] solutions, then one int: the singular-system count
+  const size_t sol_bytes = (size_t)pairs * 2 * n * sizeof(double);
+  DVSG_HIP(hipMalloc(&dtmp, sol_bytes + sizeof(int)));
+  int *flag = reinterpret_cast<int *>(reinterpret_cast<char *>(dtmp) + sol_bytes);
+  int n_singular = 0;
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), as_stream(stream));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(pairs), dim3(64), 0, as_stream(stream), coord, 0L, scratch, 0, P,
+                       static_cast<float *>(nullptr), dtmp, flag);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(winv_cols, dtmp, (size_t)P * n * sizeof(double), hipMemcpyDeviceToDevice, as_stream(stream));
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_singular, flag, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream));
   if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
   (void)hipFree(dtmp);
   if (e != hipSuccess) return fail(DVSG_ERR_HIP, "tps_inverse_columns: %s", hipGetErrorString(e));
+  if (n_singular) return fail(DVSG_ERR_INVALID_ARG, "TPS system of the control points is not invertible");
   return DVSG_OK;
 }
 
@@ -701,7 +732,13 @@ extern "C" {
 
 int dvsg_tps_solve_f32(const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
                        float *T, void *stream) {
-  return tps_solve_impl(coord, (long)P * 2, rhs, rhs_is_vector, B, P, T, stream);
+  return tps_solve_impl(coord, (long)P * 2, rhs, rhs_is_vector, B, P, T, nullptr, stream);
+}
+
+int dvsg_tps_solve_checked_f32(const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
+                               float *T, int *n_singular, void *stream) {
+  DVSG_REQUIRE(n_singular, "dvsg_tps_solve_checked_f32: NULL n_singular");
+  return tps_solve_impl(coord, (long)P * 2, rhs, rhs_is_vector, B, P, T, n_singular, stream);
 }
 
 int dvsg_tps_warp_f32(const float *U, const float *coord, const float *T, int B, int H, int W,

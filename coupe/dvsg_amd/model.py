@@ -129,6 +129,9 @@ class StabNet:
             patches = as_dev(feed[self.inputs['patches_t']])
             if patches.dim() != 4 or patches.shape[3] != 3 * self.sample_num:
                 raise ValueError("patches_t must be [B,H,W,%d]" % (3 * self.sample_num))
+            if 3 * self.sample_num != self.locnet.in_channels:
+                raise ValueError("get_evaluation_model(%d) feeds %d channels but conv1 of the loaded checkpoint "
+                                 "has %d" % (self.sample_num, 3 * self.sample_num, self.locnet.in_channels))
         need_warp = any(k in keys for k in ('s_t_pred', 'x_offset_t', 'y_offset_t', 's_t_pred_mask'))
         if need_warp or 'V_src' in keys:
             if self.inputs['u_t'] not in feed:

@@ -86,7 +86,24 @@ class LocNet(object):
         caller's stream sees one fork / join."""
         import torch
         fn = _entry("dvsg_stabilize", precision)
+        if u_t.dim() != 4 or u_t.shape[3] != 3:
+            raise ValueError("u_t must be [B,H,W,3], got %s" % (tuple(u_t.shape),))
         B, H, W, _ = u_t.shape
+        # the C entry point takes no channel count: conv1 reads `in_channels` floats per pixel, so a
+        # narrower window (e.g. a 5-entry skip_length) would be read past its end
+        if tuple(patches.shape) != (B, H, W, self.in_channels):
+            raise ValueError("patches_t must be [%d,%d,%d,%d] (conv1 of the loaded checkpoint has %d input "
+                             "channels), got %s" % (B, H, W, self.in_channels, self.in_channels, tuple(patches.shape)))
+        if tuple(out.shape) != (B, H, W, 3) or F.numel() != B * 50:
+            raise ValueError("out must be [B,H,W,3] and F_t [B,25,2]")
+        for name, t, n in (("patches_t", patches, None), ("u_t", u_t, None), ("s_t_pred", out, None), ("F_t", F, None),
+                           ("x_s", xs, B * H * W), ("y_s", ys, B * H * W)):
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError("%s must be a contiguous float32 device tensor" % name)
+            if n is not None and t.numel() != n:
+                raise ValueError("%s must hold B*H*W = %d values" % (name, n))
         if n_streams <= 1 or B < 2 * n_streams:
             ws, nbytes = self.workspace(B, H, W)
             _lib.call(fn, self.handle, ptr(patches), ptr(u_t), B, H, W, ptr(out), ptr(F),
@@ -130,7 +147,14 @@ class LocNet(object):
         B, H, W, C = t.shape
         ws, nbytes = self.workspace(B, H, W)
         h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        cap = B * max(h1 * w1 * 64, ((h1 + 1) // 2) * ((w1 + 1) // 2) * 256)
+        h, w = (h1 + 1) // 2, (w1 + 1) // 2
+        cap = max(h1 * w1 * 64, h * w * 64)
+        for base, units, last_stride in ((64, 3, 2), (128, 4, 2), (256, 6, 2), (512, 3, 1)):
+            for u in range(1, units + 1):   # tiny frames: h*w*depth does not shrink monotonically
+                s = last_stride if u == units else 1
+                h, w = (h - 1) // s + 1, (w - 1) // s + 1
+                cap = max(cap, h * w * base * 4)
+        cap *= B
         buf = empty((cap,), t)
         dims = (ctypes.c_int * 3)()
         _lib.call(_entry("dvsg_locnet_forward_tap", precision), self.handle, ptr(t), B, H, W, int(stage), ptr(buf), cap * 4,

@@ -59,6 +59,14 @@ const char *dvsg_target_arch(void);
 int dvsg_tps_solve_f32(const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
                        float *T, void *stream);
 
+/* As above, for callers that want tf.matrix_inverse's error behaviour (ThinPlateSpline.py:159
+ * raises InvalidArgument "Input is not invertible" on repeated / collinear control points): the
+ * number of samples whose system has a pivot below 1e-13 x max|W| is ADDED to the device int
+ * *n_singular (zero it first; read it after the stream has run).  Either way such a sample's T is
+ * NaN, never a finite garbage map. */
+int dvsg_tps_solve_checked_f32(const float *coord, const float *rhs, int rhs_is_vector, int B, int P,
+                               float *T, int *n_singular, void *stream);
+
 /* `_transform` + `_meshgrid` + `_interpolate` fused (ThinPlateSpline.py:30-141): for every
  * output pixel evaluate [1, x_t, y_t, r_0..r_{P-1}], (x_s, y_s) = T . basis, then sampler A
  * (coords scaled by W/2, indices clipped BEFORE the weights).  U [B,H,W,C]; coord [B,P,2];

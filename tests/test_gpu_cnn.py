@@ -45,6 +45,47 @@ def test_every_stage_matches_oracle(net, synthetic_weights, B, H, W):
     assert np.abs(F - F_ref).max() <= 1e-5     # SURVEY.md 8d parity target for the f32 path
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 8, 8), (2, 6, 6), (1, 20, 4), (3, 1, 1), (1, 4, 37)])
+def test_tiny_frames_match_oracle(net, synthetic_weights, B, H, W):
+    """Frames so small that h*w*channels GROWS in the later blocks (the ceil in (h-1)/stride+1: an
+    8x8 frame is 1x1x2048 in block 4 but only 2x2x256 in block 1).  The workspace plan sizes every
+    buffer by its largest tenant; before that fix r1 spilled into r2 and a unit's output into its
+    own input here, silently."""
+    x = inputs.window_frames(241, B, H, W)
+    taps = {}
+    F_ref = onet.localizationNet(x, 25, synthetic_weights, taps=taps)
+    for stage, name in ((4, "block1/unit_3"), (8, "block2/unit_4"), (14, "block3/unit_6"), (17, "block4/unit_3")):
+        act = net.tap(x, stage).cpu().numpy()
+        ref = taps[name]
+        assert act.shape == ref.shape, name
+        assert np.abs(act - ref).max() <= 2e-5 * np.abs(ref).max(), name
+    assert np.abs(net.forward(x).cpu().numpy() - F_ref).max() <= 1e-5
+
+
+def test_window_width_must_match_the_checkpoint(net, synthetic_weights):
+    """The C entry points take no channel count (conv1 reads 21 floats per pixel): a narrower window
+    must be rejected on the host, not read past its end."""
+    import torch
+    from coupe.dvsg_amd.clip import stabilize_clip
+    from coupe.dvsg_amd.model import Session, StabNet
+    H, W = 32, 48
+    x = inputs.window_frames(251, 1, H, W)
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    ins, outs = model.get_evaluation_model(5)
+    with pytest.raises(ValueError, match="conv1"):
+        Session().run(outs["s_t_pred"], {ins["patches_t"]: x[..., :15], ins["u_t"]: x[..., 12:15]})
+    with pytest.raises(ValueError, match="conv1"):
+        stabilize_clip(model, Session(), inputs.smooth_frames(252, 2, H, W), skip_length=(0, 16, 24, 28, 32))
+    dev = torch.device("cuda:0")
+    p15 = torch.zeros((1, H, W, 15), device=dev)
+    u = torch.zeros((1, H, W, 3), device=dev)
+    with pytest.raises(ValueError, match="patches_t"):
+        net.stabilize(p15, u, torch.empty_like(u), torch.empty((1, 25, 2), device=dev))
+    with pytest.raises(ValueError, match="contiguous float32"):
+        net.stabilize(torch.zeros((1, H, W, 21), device=dev, dtype=torch.float64), u, torch.empty_like(u),
+                      torch.empty((1, 25, 2), device=dev))
+
+
 def test_head_batch_chunks(net, synthetic_weights):
     """B > 16 exercises the chunked dense head."""
     B, H, W = 19, 32, 32

@@ -149,6 +149,33 @@ def test_tps_known_answers(dev):
     assert np.abs(x - (xt + 0.125)).max() < 5e-6 and np.abs(y - (yt - 0.25)).max() < 5e-6
 
 
+def test_singular_control_points_raise(dev):
+    """tf.matrix_inverse (ThinPlateSpline.py:159) raises InvalidArgument on a non-invertible system:
+    repeated or collinear control points.  The facade raises too; the raw stream-ordered entry
+    point marks such a sample's T as NaN (never a finite garbage map) and leaves the others alone."""
+    import torch
+    from coupe.dvsg_amd import DvsgError, _lib
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline, solve_system
+    B, H, W = 3, 24, 32
+    U = inputs.smooth_frames(35, B, H, W)
+    coord = inputs.v_src(B).copy()
+    vec = inputs.control_vectors(36, B)
+    good = solve_system(coord, vec)
+    coord[1, 7] = coord[1, 3]                      # sample 1: a repeated control point
+    with pytest.raises(DvsgError, match="1 of 3 samples"):
+        ThinPlateSpline(U, coord, vec, (H, W))
+    line = inputs.v_src(1).copy()
+    line[0, :, 1] = 0.5 * line[0, :, 0]            # all 25 points on one line
+    with pytest.raises(DvsgError, match="not invertible"):
+        solve_system(line, vec[:1])
+    ct, vt = torch.from_numpy(coord).to(dev), torch.from_numpy(vec).to(dev)
+    T = torch.zeros((B, 2, 28), device=dev)
+    _lib.call("dvsg_tps_solve_f32", ct.data_ptr(), vt.data_ptr(), 1, B, 25, T.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    T = T.cpu().numpy()
+    assert np.isnan(T[1]).all() and np.array_equal(T[0], good[0]) and np.array_equal(T[2], good[2])
+
+
 def test_tps_torch_tensors_stay_on_device(dev):
     import torch
     from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
