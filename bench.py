@@ -8,10 +8,17 @@ TPS solve -> TPS grid + sampler A) over one batch of 16 synthetic 7-frame window
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: windows are independent, so each rank stabilises its own batch
-(weak scaling, no data-path collective) and the stabilised frames of every step are gathered
-to rank 0 over RCCL (one `gather` per step, issued asynchronously so that it overlaps the
-next step's kernels; the last one is waited for inside the timed region).
+Both forms work: started bare with --gpus N > 1 (no WORLD_SIZE in the environment) this script
+spawns the N ranks itself -- before anything in the parent touches the GPU -- relays rank 0's JSON
+line and exits non-zero if any rank does.
+
+Multi-GPU (N > 1) is BASELINE.json configs[3]: every rank owns a contiguous shard of 64 independent
+720p windows (512 at N = 8), one step stabilises the shard in four `dvsg_stabilize_f32`
+calls of 16 windows -- the very call configs[1] times at N = 1, so per-GPU work per call is the same
+at every N (weak scaling) -- with no data-path collective, and the stabilised frames of every step
+are gathered to rank 0 over RCCL (one `gather` of [64,720,1280,3] per rank and step, issued
+asynchronously so that it overlaps the next step's kernels; the last one is waited for inside the
+timed region).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with hipEvents around every launch
 of the dominant kernel class inside the timed region; `cpu_baseline` times the CPU oracle
@@ -88,8 +95,23 @@ def usable_cores():
     return min(n, int(os.environ.get("DVSG_BENCH_CPU_THREADS", "16")))
 
 
+def cpu_model():
+    """CPU model string of the box (SURVEY.md 8d asks for core count AND model)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_baseline(weights, H, W, budget_s=20.0):
-    """CPU oracle ("port": torch-CPU CNN + NumPy TPS) on one 720p window at a time."""
+    """CPU oracle ("port": torch-CPU CNN + NumPy TPS) on one 720p window at a time.  The CNN and the
+    warp are also timed apart (the warp is one NumPy thread: SURVEY.md 8d's warp-only baseline);
+    tools/cpu_baseline_full.py adds the B=16 pass, too long for a default bench run."""
     from oracle.cnn_torch import TorchLocNet
     from oracle.thin_plate_spline import ThinPlateSpline as o_tps
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -99,23 +121,27 @@ def cpu_baseline(weights, H, W, budget_s=20.0):
     net = TorchLocNet(weights)
     x = inputs.window_frames(1234, 1, H, W)
     vsrc = inputs.v_src(1)
-    times = []
+    times, cnn_t, warp_t = [], [], []
     t_start = time.perf_counter()
     runs = 0
     while True:
         t0 = time.perf_counter()
         Ft = net.forward(x)
+        t1 = time.perf_counter()
         o_tps(x[..., 18:], vsrc, Ft, (H, W))
-        dt = time.perf_counter() - t0
+        t2 = time.perf_counter()
         runs += 1
         if runs > 1:           # first run is warm-up
-            times.append(dt)
+            times.append(t2 - t0)
+            cnn_t.append(t1 - t0)
+            warp_t.append(t2 - t1)
         if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 5:
             break
     med = float(np.median(times))
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d single-window (B=1, %dx%d) passes of the torch-CPU CNN + NumPy TPS oracle after 1 "
-                      "warm-up; median" % (len(times), W, H)}
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "cnn_ms_per_frame": 1e3 * float(np.median(cnn_t)), "warp_ms_per_frame": 1e3 * float(np.median(warp_t)),
+            "sample": "%d single-window (B=1, %dx%d) passes of the torch-CPU CNN (%d threads) + NumPy TPS oracle "
+                      "(1 thread) after 1 warm-up; median" % (len(times), W, H, cores)}
 
 
 def cpu_baseline_flow(H, W, budget_s=10.0):
@@ -132,8 +158,66 @@ def cpu_baseline_flow(H, W, budget_s=10.0):
         o_tf_warp(im, flow, H, W)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times[1:] if len(times) > 2 else times))
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d single-frame (%dx%d) passes of the NumPy tf_warp oracle; median" % (len(times), W, H)}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS
+    process, which never touches the GPU itself (no exec of a GPU-initialised process, no HIP call
+    in the parent), relay rank 0's stdout (the JSON line) and fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = b""
+    rc = 0
+    try:
+        # rank 0's stdout is small (one line); a failing peer must not leave the others waiting in a
+        # collective forever, so poll everybody and stop the rest once one rank has failed
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        eof = False
+        while True:
+            if not eof:
+                for key, _ in sel.select(timeout=0.5):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        out0 += chunk
+                    else:
+                        eof = True
+                        sel.unregister(key.fileobj)
+            else:
+                time.sleep(0.2)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 1
+                break
+            if all(c == 0 for c in codes) and eof:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    if rc:
+        raise SystemExit(rc)
 
 
 def main():
@@ -144,7 +228,12 @@ def main():
     ap.add_argument("--workload", default="stabilize", choices=["stabilize", "tf_warp"],
                     help="stabilize: the headline path (CNN + TPS + sampler, configs[1]); tf_warp: the optical-flow "
                          "warp alone (configs[2], batch 64)")
-    ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (stabilize) / 64 (tf_warp)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="windows per GPU and step; default 16 (stabilize, 1 GPU: configs[1]), 64 (stabilize, N > 1 "
+                         "GPUs: configs[3]'s shard) / 64 (tf_warp)")
+    ap.add_argument("--call-batch", type=int, default=None,
+                    help="windows per dvsg_stabilize call; default: the whole batch at 1 GPU, 16 at N > 1 (a rank's "
+                         "64-window shard runs as four calls of the configs[1] size)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--prof-class", type=int, default=None,
@@ -158,15 +247,17 @@ def main():
                          "but concurrent launches make the per-kernel hipEvent durations of `roofline` meaningless")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     # Rehearsal knobs for a one-GPU box (the real multi-GPU run uses neither): DVSG_BENCH_BACKEND=gloo
     # stages the gather through host memory, DVSG_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0.
+    if os.environ.get("DVSG_BENCH_FAIL_RANK") == str(rank) and world > 1:   # test hook: a rank that dies early
+        raise SystemExit("rank %d: failing on request (DVSG_BENCH_FAIL_RANK)" % rank)
     backend = os.environ.get("DVSG_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("DVSG_BENCH_SHARE_DEVICE") == "1" else local_rank
     torch.cuda.set_device(dev_index)
@@ -184,10 +275,11 @@ def main():
 
     flow_mode = args.workload == "tf_warp"
     if args.batch is None:
-        args.batch = 64 if flow_mode else 16
+        args.batch = 64 if (flow_mode or world > 1) else 16
     if args.prof_class is None:
         args.prof_class = 7 if flow_mode else 1
     B, H, W = args.batch, args.height, args.width
+    CB = args.call_batch or (B if world == 1 else 16)
     weights = net = patches = u_t = flow = None
     if flow_mode:
         # SURVEY.md 8d cfg 3: frames as cfg 2; flow ~ N(0, 4 px) smoothed by a 15-px box, 1 % of the pixels out of bounds
@@ -223,7 +315,10 @@ def main():
             _lib.call("dvsg_flow_warp_f32", u_t.data_ptr(), flow.data_ptr(), B, H, W, 3, out.data_ptr(),
                       torch.cuda.current_stream().cuda_stream)
         else:
-            net.stabilize(patches, u_t, out, F_t, n_streams=args.streams, precision=args.precision)  # dvsg_stabilize_*
+            for b0 in range(0, B, CB):   # dvsg_stabilize_*, CB windows per call
+                b1 = min(B, b0 + CB)
+                net.stabilize(patches[b0:b1], u_t[b0:b1], out[b0:b1], F_t[b0:b1], n_streams=args.streams,
+                              precision=args.precision)
         if dist is not None and not args.no_gather:
             if on_host:   # rehearsal path: synchronous, through host memory
                 dist.gather(out.cpu(), gather_bufs[slot] if rank == 0 else None, dst=0)
@@ -297,6 +392,8 @@ def main():
             which = "configs[4]"
         elif world > 1 and (B * world, H, W) == (512, 720, 1280):
             which = "configs[3]"
+        elif world > 1 and (B, H, W) == (64, 720, 1280):
+            which = "configs[3] shard (64 windows per GPU) on %d of its 8 GPUs" % world
         else:
             which = "non-BASELINE shape"
         line = {
@@ -308,7 +405,10 @@ def main():
             "config": {"workload": ("%s: batch=%d %dx%d frames, optical-flow warp (warp_with_optical_flow.tf_warp) per GPU"
                                     if flow_mode else
                                     "%s: batch=%d %dx%d 7-frame windows, full CNN+TPS+bilinear warp per GPU") % (which, B, W, H),
-                       "batch_per_gpu": B, "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
+                       "batch_per_gpu": B, "windows_per_call": CB, "windows_per_step": B * world,
+                       "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
+                       "ranks_seen": dist.get_world_size() if dist is not None else 1,
+                       "backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
                        "gather": bool(dist is not None and not args.no_gather), "streams_per_gpu": args.streams,
                        "weights": "n/a" if flow_mode else "synthetic seed 0 (reference ships no checkpoint)"},
             "roofline": roofline,

@@ -44,23 +44,31 @@ def sharded_map(n, batch, produce, frame_shape, like, group=None, dst=0):
     local = torch.cat(outs, 0) if outs else ref.new_zeros((0,) + tuple(frame_shape))
     if world == 1:
         return local
-    # gather needs equal shapes: pad every shard to the largest one
-    cap = -(-n // world)
-    padded = local.new_zeros((cap,) + tuple(frame_shape))
-    padded[:local.shape[0]] = local
-    back = padded.device
-    if padded.is_cuda and dist.get_backend(group) != "nccl":
-        padded = padded.cpu()  # rehearsal backends (gloo) gather through host memory; RCCL stays on the device
-    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bufs, dst=dst, group=group)
+    # One exchange at the end, only real rows: every rank that owns windows sends its slab straight
+    # to `dst` (its own xGMI link on RCCL), which receives each slab in place -- no padding to a
+    # common shard size, no copy after the receive.
+    on_host = local.is_cuda and dist.get_backend(group) != "nccl"
+    back = local.device
+    if on_host:
+        local = local.cpu()   # rehearsal backends (gloo) exchange through host memory; RCCL stays on the device
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank != dst:
+        if local.shape[0]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local.contiguous(), peer(dst), group)]):
+                req.wait()
         return None
-    bufs = [t.to(back) for t in bufs]
-    parts = []
+    full = local.new_empty((n,) + tuple(frame_shape))
+    ops = []
     for r in range(world):
         rlo, rhi = shard_range(n, world, r)
-        parts.append(bufs[r][:rhi - rlo])
-    return torch.cat(parts, 0)
+        if r == dst:
+            full[rlo:rhi] = local
+        elif rhi > rlo:
+            ops.append(dist.P2POp(dist.irecv, full[rlo:rhi], peer(r), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return full.to(back) if on_host else full
 
 
 def stabilize_windows_sharded(run_fn, patches_t, u_t, batch=16, group=None, dst=0):

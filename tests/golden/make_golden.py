@@ -29,7 +29,11 @@ from oracle import warp_with_optical_flow as oflow  # noqa: E402
 CASES = {
     "warps": dict(B=2, H=32, W=48),
     "locnet": dict(B=2, H=64, W=96),
-    "clip": dict(N=3, H=32, W=48),
+    # N ~ 40 at tiny resolution, so that every window slot (offsets 0, 16, 24,
+    # 28, 30, 31, 32; eval.py:101-124) reads a stabilised frame at least once (slot 0 from step 33 on)
+    "clip": dict(N=40, H=32, W=48),
+    # BASELINE.json configs[0]: one 256x256 window through the evaluation graph (eval.py path)
+    "cfg0_256": dict(B=1, H=256, W=256),
 }
 
 
@@ -76,12 +80,27 @@ def clip_case(weights):
     return dict(stabilised=outs, side_by_side=side)
 
 
+def cfg0_case(weights):
+    """configs[0]: a single 256x256 7-frame window, `sess.run([F_t, s_t_pred, x_offset_t, y_offset_t])`.
+    The source grid is kept as the packed border-discontinuity mask it is needed for (sampler A's
+    jump pixels, SURVEY.md section 7 hard part 3) plus a 1-in-16 subsample."""
+    c = CASES["cfg0_256"]
+    B, H, W = c["B"], c["H"], c["W"]
+    x = inputs.window_frames(5001, B, H, W)
+    F, s_t_pred, xs, ys = omodel.StabNet(H, W).run(weights, x, x[..., 18:],
+                                                   fetch=("F_t", "s_t_pred", "x_offset_t", "y_offset_t"))
+    mask = otps.border_discontinuity_mask(xs, ys, H, W, delta=3e-2)
+    return dict(F_t=F, s_t_pred=s_t_pred, border_mask_bits=np.packbits(mask),
+                xs_sub=xs[::16].astype(np.float32), ys_sub=ys[::16].astype(np.float32))
+
+
 def main():
     weights = make_synthetic_weights(seed=0)
     np.savez_compressed(os.path.join(HERE, "warps.npz"), **warps_case())
     np.savez_compressed(os.path.join(HERE, "locnet.npz"), **locnet_case(weights))
     np.savez_compressed(os.path.join(HERE, "clip.npz"), **clip_case(weights))
-    for f in ("warps.npz", "locnet.npz", "clip.npz"):
+    np.savez_compressed(os.path.join(HERE, "cfg0_256.npz"), **cfg0_case(weights))
+    for f in ("warps.npz", "locnet.npz", "clip.npz", "cfg0_256.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

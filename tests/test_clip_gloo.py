@@ -62,7 +62,7 @@ def _worker(rank, world, port, n, result_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 10), (2, 7), (3, 8)])
+@pytest.mark.parametrize("world,n", [(2, 10), (2, 7), (3, 8), (3, 2)])
 def test_sharded_windows_gather_in_order(tmp_path, world, n):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)

@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
-                         timeout=600, cwd=ROOT)
+                         timeout=600, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -46,3 +46,35 @@ def test_bench_tf_warp_workload():
     d = _run("--workload", "tf_warp", "--steps", "2", "--warmup", "1", "--batch", "3", "--height", "96", "--width", "160")
     assert d["metric"].startswith("tf_warp") and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
     assert d["roofline"]["kernel"] == "stn_kernel" and d["roofline"]["launches"] == 2 and d["cpu_baseline"]["cores"] == 1
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver runs): the script spawns
+    its two ranks itself, each stabilises its shard in calls of `windows_per_call`, the frames are
+    gathered to rank 0 every step, and ONE JSON line comes back.  Rehearsal on the one-GPU box: both
+    ranks share cuda:0 and the gather goes through gloo (the real run uses RCCL, one GPU per rank)."""
+    env = {"DVSG_BENCH_BACKEND": "gloo", "DVSG_BENCH_SHARE_DEVICE": "1"}
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "6", "--call-batch", "4", "--height", "96", "--width", "160"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env_clean, **env))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["gather"] is True and c["backend"] == "gloo"
+    assert c["batch_per_gpu"] == 6 and c["windows_per_call"] == 4 and c["windows_per_step"] == 12
+    assert abs(d["value"] - 12 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d and d["roofline"]["launches"] > 0
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that dies must fail the whole run (non-zero exit, no JSON line), not hang it."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env = dict(env_clean, DVSG_BENCH_BACKEND="gloo", DVSG_BENCH_SHARE_DEVICE="1", DVSG_BENCH_FAIL_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "2", "--height", "64", "--width", "96"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

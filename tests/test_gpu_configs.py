@@ -1,0 +1,184 @@
+"""GPU parity at the five workloads BASELINE.json names, each at its full size through the C ABI.
+
+configs[0]  one 256x256 window through the evaluation graph, against the committed golden
+configs[1]  B=16 1280x720: `dvsg_stabilize_f32` end to end, two windows against the CPU oracle
+configs[2]  B=64 tf_warp: tests/test_gpu_fullsize.py::test_tf_warp_b64_720p_properties
+configs[3]  one rank's 64-window 720p shard of the 512-window job (the 8-GPU run itself is the
+            driver's: bench.py --gpus 8), in batches of 16 through `stabilize_windows_sharded`
+configs[4]  B=32 3840x2160 through `dvsg_stabilize_f16`: determinism, batch invariance, the
+            identity-warp property of the 4K TPS stage, F_t of two windows against the CPU oracle
+Where the NumPy / torch-CPU oracle is too slow for every sample, size-independent properties cover
+the whole batch and the oracle spot-checks single windows.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import inputs
+from oracle import thin_plate_spline as otps
+from oracle.cnn_torch import TorchLocNet
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+H720, W720 = 720, 1280
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _gpu_windows(B, H, W, seed, dev):
+    """bench.py's device-side synthetic windows (band-limited noise, 7 shifted views)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench.gpu_windows(B, H, W, seed, dev)
+
+
+def _oracle_window(weights, x1, H, W):
+    """CPU oracle of one window [1,H,W,21] (torch-CPU CNN + NumPy TPS): F_t, s_t_pred, x_s, y_s."""
+    F = TorchLocNet(weights).forward(x1)
+    pred, xs, ys = otps.ThinPlateSpline(x1[..., 18:], inputs.v_src(1), F, (H, W))
+    return F, pred, xs, ys
+
+
+def test_cfg0_single_256_window(synthetic_weights):
+    """configs[0]: `sess.run` on one 256x256 window, NumPy in / NumPy out as eval.py:106-110 does."""
+    from coupe.dvsg_amd.model import Session, StabNet
+    with np.load(os.path.join(GOLD, "cfg0_256.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    H = W = 256
+    x = inputs.window_frames(5001, 1, H, W)
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    ins, outs = model.get_evaluation_model(7)
+    pred, F, xs, ys = Session().run([outs["s_t_pred"], outs["F_t"], outs["x_offset_t"], outs["y_offset_t"]],
+                                    {ins["patches_t"]: x, ins["u_t"]: x[..., 18:]})
+    assert isinstance(pred, np.ndarray) and pred.shape == (1, H, W, 3) and F.shape == (1, 25, 2)
+    assert np.abs(F - g["F_t"]).max() <= 1e-5
+    gerr = max(np.abs(xs[::16] - g["xs_sub"]).max() * W / 2, np.abs(ys[::16] - g["ys_sub"]).max() * H / 2)
+    assert gerr < 2e-2, "grid error %.3g px" % gerr
+    mask = np.unpackbits(g["border_mask_bits"])[:H * W].astype(bool).reshape(1, H, W)
+    err = np.abs(pred - g["s_t_pred"]).max(axis=3)
+    assert err[~mask].max() < 1e-3, "pixel error %.3g" % err[~mask].max()
+    assert mask.mean() < 0.02
+
+
+def test_cfg1_stabilize_b16_720p_end_to_end(dev, synthetic_weights):
+    """configs[1]: the benchmarked call itself -- ONE `dvsg_stabilize_f32` over B=16 720p windows --
+    with two of the windows checked end to end against the CPU oracle: F_t <= 1e-5, source grid
+    < 2e-2 px, warped pixels < 1e-3 outside the counted sampler-A border-discontinuity pixels."""
+    import torch
+    from coupe.dvsg_amd.networks import LocNet
+    B, H, W = 16, H720, W720
+    x = _gpu_windows(B, H, W, 77, dev)
+    u = x[..., 18:].contiguous()
+    net = LocNet(synthetic_weights)
+    out = torch.empty((B, H, W, 3), device=dev)
+    F = torch.empty((B, 25, 2), device=dev)
+    xs = torch.empty((B * H * W,), device=dev)
+    ys = torch.empty_like(xs)
+    net.stabilize(x, u, out, F, xs, ys)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    xs, ys = xs.reshape(B, -1), ys.reshape(B, -1)
+    for b in (3, 12):
+        rF, rpred, rxs, rys = _oracle_window(synthetic_weights, x[b:b + 1].cpu().numpy(), H, W)
+        assert np.abs(F[b:b + 1].cpu().numpy() - rF).max() <= 1e-5
+        gerr = max(np.abs(xs[b].cpu().numpy() - rxs).max() * W / 2, np.abs(ys[b].cpu().numpy() - rys).max() * H / 2)
+        assert gerr < 2e-2, "window %d: grid error %.3g px" % (b, gerr)
+        mask = otps.border_discontinuity_mask(rxs, rys, H, W, delta=3e-2).reshape(H, W)
+        err = np.abs(out[b].cpu().numpy() - rpred[0]).max(axis=2)
+        assert err[~mask].max() < 1e-3, "window %d: pixel error %.3g" % (b, err[~mask].max())
+        assert mask.mean() < 0.01
+
+
+def test_cfg3_one_rank_shard_of_64_windows(dev, synthetic_weights):
+    """configs[3] rehearsal on one card: rank 3's 64-window shard of the 512-window job, in batches
+    of 16 through `stabilize_windows_sharded` (a one-rank process group, so the sharding and gather
+    code runs), spot-checked against the CPU oracle and against a direct call."""
+    import torch
+    import torch.distributed as dist
+    from coupe.dvsg_amd.clip import shard_range, stabilize_windows_sharded
+    from coupe.dvsg_amd.model import Session, StabNet
+    H, W = H720, W720
+    lo, hi = shard_range(512, 8, 3)
+    assert (lo, hi) == (192, 256)
+    n = hi - lo
+    x = torch.cat([_gpu_windows(16, H, W, 1000 + lo + i, dev) for i in range(0, n, 16)], 0)
+    u = x[..., 18:].contiguous()
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    ins, outs = model.get_evaluation_model(7)
+    sess = Session()
+    calls = []
+
+    def run_fn(p, uu):
+        calls.append(int(p.shape[0]))
+        return sess.run(outs["s_t_pred"], {ins["patches_t"]: p, ins["u_t"]: uu})
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        res = stabilize_windows_sharded(run_fn, x, u, batch=16)
+    finally:
+        dist.destroy_process_group()
+    assert calls == [16, 16, 16, 16] and res.shape == (n, H, W, 3) and res.is_cuda
+    direct = run_fn(x[32:48], u[32:48])
+    assert torch.equal(direct, res[32:48])
+    for b in (5, 58):
+        _, rpred, rxs, rys = _oracle_window(synthetic_weights, x[b:b + 1].cpu().numpy(), H, W)
+        mask = otps.border_discontinuity_mask(rxs, rys, H, W, delta=3e-2).reshape(H, W)
+        err = np.abs(res[b].cpu().numpy() - rpred[0]).max(axis=2)
+        assert err[~mask].max() < 1e-3, "window %d: pixel error %.3g" % (b, err[~mask].max())
+
+
+def test_cfg4_b32_4k_f16(dev, synthetic_weights):
+    """configs[4]: B=32 3840x2160 windows in ONE `dvsg_stabilize_f16` call (22 GB of windows and a
+    ~60 GB workspace fit the 288 GB of HBM: no sub-batching).  float16 storage cannot be bit-compatible
+    with the float32 reference; stated bounds against the float32 CPU oracle at this size:
+    F_t < 2e-3 (|F_t| ~ 0.1).  Exact properties: bitwise run-to-run determinism, batch invariance up to
+    accumulation order, and the identity map of the (float32) 4K TPS stage."""
+    import torch
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
+    from coupe.dvsg_amd.networks import LocNet
+    B, H, W = 32, 2160, 3840
+    net = LocNet(synthetic_weights)
+    x = torch.cat([_gpu_windows(8, H, W, 400 + i, dev) for i in range(4)], 0)
+    u = x[..., 18:].contiguous()
+    out = torch.empty((B, H, W, 3), device=dev)
+    F = torch.empty((B, 25, 2), device=dev)
+    net.stabilize(x, u, out, F, precision="f16")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(F).all())
+    assert -1e-4 <= float(out.min()) and float(out.max()) <= 1.0 + 1e-4
+    out2 = torch.empty_like(out)
+    F2 = torch.empty_like(F)
+    net.stabilize(x, u, out2, F2, precision="f16")
+    torch.cuda.synchronize()
+    assert torch.equal(F, F2) and torch.equal(out, out2)                # deterministic
+    del out2
+    o1 = torch.empty((1, H, W, 3), device=dev)
+    F1 = torch.empty((1, 25, 2), device=dev)
+    net.stabilize(x[21:22], u[21:22], o1, F1, precision="f16")          # window 21 alone
+    assert float((F1 - F[21:22]).abs().max()) <= 2e-5
+    assert float(((o1 - out[21:22]).abs() > 1e-3).float().mean()) < 1e-3
+    ref = TorchLocNet(synthetic_weights)
+    for b in (0, 21):
+        rF = ref.forward(x[b:b + 1].cpu().numpy())
+        err = np.abs(F[b:b + 1].cpu().numpy() - rF).max()
+        assert err < 2e-3, "window %d: f16 F_t error %.3g" % (b, err)
+    del out, o1
+    # the warp stage of configs[4] (float32 in both modes) at 4K: zero control vectors -> identity grid
+    coord = torch.from_numpy(inputs.v_src(2)).to(dev)
+    o, xg, yg = ThinPlateSpline(u[:2], coord, torch.zeros_like(coord), (H, W))
+    xt = torch.linspace(-1, 1, W, device=dev).repeat(H)
+    yt = torch.linspace(-1, 1, H, device=dev).repeat_interleave(W)
+    assert float((xg.reshape(2, -1) - xt).abs().max()) < 5e-6 and float((yg.reshape(2, -1) - yt).abs().max()) < 5e-6
+    # identity grid = resampling at j * W / (W - 1): interior pixels stay within one pixel's gradient
+    assert float((o[:, 1:-1, 1:-1] - u[:2, 1:-1, 1:-1]).abs().max()) < 0.05

@@ -47,21 +47,30 @@ def test_locnet_against_golden(synthetic_weights):
 
 
 def test_eval_clip_loop(synthetic_weights):
-    """eval.py:93-124 with the history on the device: same stabilised sequence as the oracle
-    (the recurrence feeds each output back, so errors compound over the steps)."""
-    from coupe.dvsg_amd.clip import stabilize_clip
+    """eval.py:93-124 with the history on the device, N = 40 frames: every
+    window slot -- offsets 0, 16, 24, 28, 30, 31, 32 -- reads stabilised history at least once (slot 0
+    from step 33 on).  The recurrence feeds each output back, so a float32 re-association difference
+    in F_t compounds over the steps and a pixel sitting on sampler A's border jump can flip and stay
+    flipped: per step, the median error stays at float32 noise and the flipped pixels are counted."""
+    from coupe.dvsg_amd.clip import stabilize_clip, window_index_table
     from coupe.dvsg_amd.model import Session, StabNet
     g = _load("clip.npz")
-    H, W = 32, 48
-    frames = inputs.smooth_frames(3001, 3, H, W)
+    N, H, W = 40, 32, 48
+    table = window_index_table(N)
+    for s in range(6):     # every history slot reads from the stabilised half of the pool at some step
+        assert (table[1:, s] > N).any()
+    frames = inputs.smooth_frames(3001, N, H, W)
     model = StabNet(H, W).load_weights(synthetic_weights)
     model.get_evaluation_model(7)
     out, side = stabilize_clip(model, Session(), frames, side_by_side=True)
-    assert out.shape == (3, H, W, 3) and side.shape == (3, H, 2 * W, 3) and side.dtype == np.uint8
-    ref, rside = omodel.eval_clip(synthetic_weights, frames, H, W)
-    assert np.abs(out - ref).max() < 2e-2             # border-discontinuity pixels included
-    assert np.median(np.abs(out - ref)) < 1e-5
-    assert np.abs(out - g["stabilised"]).max() < 2e-2
+    assert out.shape == (N, H, W, 3) and side.shape == (N, H, 2 * W, 3) and side.dtype == np.uint8
+    ref, rside = g["stabilised"], g["side_by_side"]
+    err = np.abs(out - ref).reshape(N, -1)
+    med, mx, bad = np.median(err, axis=1), err.max(axis=1), (err > 1e-3).mean(axis=1)
+    print("clip N=40 per-step error: median max %.2e (step %d), max %.2e (step %d), pixels > 1e-3: max %.3f%%"
+          % (med.max(), med.argmax(), mx.max(), mx.argmax(), 100 * bad.max()))
+    assert med.max() < 1e-5, "median error per step %s" % med
+    assert bad.max() < 0.02, "fraction of pixels off by > 1e-3, per step: %s" % bad
     assert np.array_equal(side[:, :, :W], rside[:, :, :W])      # left half: the unstable input
     diff = np.abs(side[:, :, W:].astype(int) - rside[:, :, W:].astype(int))
     assert (diff > 1).mean() < 0.01

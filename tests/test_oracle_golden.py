@@ -49,11 +49,32 @@ def test_locnet_golden(synthetic_weights):
 
 
 def test_clip_golden(synthetic_weights):
+    """N = 40: long enough for every window slot to read stabilised history."""
     g = _load("clip.npz")
-    frames = inputs.smooth_frames(3001, 3, 32, 48)
+    N = 40
+    frames = inputs.smooth_frames(3001, N, 32, 48)
     outs, side = omodel.eval_clip(synthetic_weights, frames, 32, 48)
-    assert outs.shape == g["stabilised"].shape == (3, 32, 48, 3)
-    assert side.shape == (3, 32, 96, 3) and side.dtype == np.uint8
-    assert np.abs(outs - g["stabilised"]).max() < 5e-3
+    assert outs.shape == g["stabilised"].shape == (N, 32, 48, 3)
+    assert side.shape == (N, 32, 96, 3) and side.dtype == np.uint8
+    # the recurrence feeds LAPACK's float32-inverse noise back 40 times; pixels on sampler A's border
+    # jump may flip (counted, not bounded)
+    diff = np.abs(outs - g["stabilised"])
+    assert np.median(diff) < 1e-6 and (diff > 5e-3).mean() < 1e-3
+    assert np.array_equal(side, g["side_by_side"]) or (side != g["side_by_side"]).mean() < 1e-3
     # left half of the side-by-side is the (unstabilised) input frame, truncating cast
     assert np.array_equal(side[0, :, :48], np.uint8(frames[0].astype(np.float64) * 255.))
+
+
+def test_cfg0_golden(synthetic_weights):
+    """BASELINE.json configs[0]: one 256x256 window through the evaluation graph on the CPU."""
+    g = _load("cfg0_256.npz")
+    H = W = 256
+    x = inputs.window_frames(5001, 1, H, W)
+    F, pred, xs, ys = omodel.StabNet(H, W).run(synthetic_weights, x, x[..., 18:],
+                                               fetch=("F_t", "s_t_pred", "x_offset_t", "y_offset_t"))
+    assert F.shape == (1, 25, 2) and pred.shape == (1, H, W, 3)
+    assert np.abs(F - g["F_t"]).max() < 5e-6
+    assert np.abs(xs[::16] - g["xs_sub"]).max() < 2e-5 and np.abs(ys[::16] - g["ys_sub"]).max() < 2e-5
+    mask = np.unpackbits(g["border_mask_bits"])[:H * W].astype(bool).reshape(1, H, W)
+    assert 0 < mask.sum() < 0.02 * H * W
+    assert np.abs(pred - g["s_t_pred"]).max(axis=3)[~mask].max() < 1e-3
