@@ -180,5 +180,13 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
     xt = torch.linspace(-1, 1, W, device=dev).repeat(H)
     yt = torch.linspace(-1, 1, H, device=dev).repeat_interleave(W)
     assert float((xg.reshape(2, -1) - xt).abs().max()) < 5e-6 and float((yg.reshape(2, -1) - yt).abs().max()) < 5e-6
-    # identity grid = resampling at j * W / (W - 1): interior pixels stay within one pixel's gradient
-    assert float((o[:, 1:-1, 1:-1] - u[:2, 1:-1, 1:-1]).abs().max()) < 0.05
+    # identity grid + sampler A = bilinear resampling at (j W / (W - 1), i H / (H - 1)) (ThinPlateSpline.py:48-49
+    # scale by W, not W - 1); last row / column excluded (they map to x = W: the clipped taps cancel)
+    xsrc = torch.arange(W - 1, device=dev, dtype=torch.float64) * (W / (W - 1.0))
+    ysrc = torch.arange(H - 1, device=dev, dtype=torch.float64) * (H / (H - 1.0))
+    x0, y0 = xsrc.floor().long(), ysrc.floor().long()
+    fx, fy = (xsrc - x0).float()[None, :, None], (ysrc - y0).float()[:, None, None]
+    u0 = u[0]
+    want = ((1 - fy) * ((1 - fx) * u0[y0][:, x0] + fx * u0[y0][:, x0 + 1])
+            + fy * ((1 - fx) * u0[y0 + 1][:, x0] + fx * u0[y0 + 1][:, x0 + 1]))
+    assert float((o[0, :H - 1, :W - 1] - want).abs().max()) < 1e-3
