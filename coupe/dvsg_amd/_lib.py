@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvsg_amd.so")
+# DVSG_AMD_LIB: A/B another build of the same ABI from tools/ (diagnostic; the product path is the in-tree library)
+LIB_PATH = os.environ.get("DVSG_AMD_LIB") or os.path.join(_HERE, "libdvsg_amd.so")
 ABI_VERSION = 1
 
 c_float_p = ctypes.POINTER(ctypes.c_float)

@@ -142,12 +142,21 @@ void conv_gemm_kernel(ConvGemmDev p) {
     // LDS chunk position lane % 8, which must receive global chunk pos ^ ((row >> 1) & 7).
     long a_off[AG];       // element offset of the pixel's (kh=0, kw=0, c=chunk) tap
     unsigned a_mask[AG];  // bit kh: input row valid, bit 4+kw: input col valid
+    // A 1x1 convolution of stride 1 -- every 1x1 layer of resnet_v1_50 -- is a plain row-major GEMM:
+    // row m starts at x + m Cin.  No pixel decomposition (three integer divisions per row group, ~100
+    // instructions, a third of the prologue of a K = 64 tile whose whole main loop is 64 MFMAs).
+    const bool dense = KS == 1 && p.stride == 1;
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
       const int row = 8 * (wave + NW * i) + lrow8;
       const int chunk = lpos ^ ((row >> 1) & 7);
       const int m = m0 + row;
       const int mm = m < p.M ? m : 0;
+      if (dense) {
+        a_off[i] = (long)mm * p.Cin + CHE * chunk;
+        a_mask[i] = m < p.M ? 0x11u : 0u;
+        continue;
+      }
       const int wo = mm % p.Wo;
       const int t = mm / p.Wo;
       const int ho = t % p.Ho;
