@@ -43,6 +43,7 @@ SIGNATURES = {
                                     ctypes.POINTER(_i), _vp, ctypes.c_size_t, _vp],
     "dvsg_stabilize_f16": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
+    "dvsg_conv_gemm_f16s": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv3x3_1x1_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dvsg_frames_u8_to_f32": [_vp, ctypes.c_size_t, _i, _vp, _vp],
@@ -86,7 +87,8 @@ def load():
     _lib = lib
     # diagnostic A/B switches for kernel experiments (see dvsg_debug_set_option in the header): they
     # change which kernels production calls select, so they only apply under an explicit DVSG_DEBUG=1
-    for env, opt in (("DVSG_CONV_VARIANT", b"conv_variant"), ("DVSG_FUSE_CONV", b"fuse_conv")):
+    for env, opt in (("DVSG_CONV_VARIANT", b"conv_variant"), ("DVSG_FUSE_CONV", b"fuse_conv"),
+                     ("DVSG_F16_SPLIT", b"f16_split")):
         if os.environ.get(env) and os.environ.get("DVSG_DEBUG") == "1":
             check(lib.dvsg_debug_set_option(opt, int(os.environ[env])), "dvsg_debug_set_option")
     return lib

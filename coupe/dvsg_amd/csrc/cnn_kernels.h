@@ -28,6 +28,7 @@ struct ConvGemm {
   int ksize, stride, pad;
   int res_H, res_W, res_stride;
   int relu;
+  int wsplit = 0;     // kF16 only: wt is the split layout [Cout/64][128][K] (64 hi rows, then 64 lo rows; conv_gemm.hip)
   // optional split-K scratch (small batches): partial-tile slabs and kSplitKMaxTiles zeroed int tickets
   void *splitk_scratch = nullptr;
   size_t splitk_scratch_bytes = 0;

@@ -85,9 +85,17 @@ struct ConvGemmDev {
   int mt_fast;     // tile order, see run_segment
 };
 
-template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, int MODE>
+// SPLIT (float16 only): the weight matrix holds, for every group of 64 output channels, 128 rows -- the
+// float16 weights of the group (hi) followed by their rounding residuals (w - hi) x 2^11, again float16
+// (lo).  A 128-wide tile is then [hi | lo] of ONE 64-channel group and the epilogue folds it to 64
+// output channels, hi + 2^-11 lo: float16 activations against effectively float32 weights.  (A float16
+// weight carries a FIXED relative error of up to 2^-12 that is the same at every pixel, so it survives
+// the global average pool; it was 9/10 of the float16 mode's error in F_t.  The scale keeps lo a
+// normal float16 whatever the matrix cores do with subnormal inputs.)
+template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN / 2, WM * WN / 2)))
 void conv_gemm_kernel(ConvGemmDev p) {
+  static_assert(!SPLIT || (sizeof(T) == 2 && BN == 128), "split weights: float16, 128-wide tiles");
   constexpr int NW = WM * WN;
   constexpr int NT = 64 * NW;
   constexpr int MI = BM / WM / 32;          // 32-row MFMA blocks per wave
@@ -279,11 +287,13 @@ void conv_gemm_kernel(ConvGemmDev p) {
 
     // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
     constexpr int LDC = BN + 4;
-    constexpr int C4 = BN / 4;       // 4-channel groups per tile row
+    constexpr int BNO = SPLIT ? BN / 2 : BN;  // output channels of the tile
+    constexpr int C4 = BNO / 4;      // 4-channel groups per output row
     constexpr int RSTEP = NT / C4;   // tile rows covered per pass
     constexpr int NROW = BM / RSTEP; // rows per thread
+    constexpr float kLoScale = 1.0f / 2048.0f;
     const int col4 = tid % C4, row0 = tid / C4;
-    const int n = n0 + 4 * col4;
+    const int n = (SPLIT ? nt * BNO : n0) + 4 * col4;
     float *Cs = reinterpret_cast<float *>(lds);
     const bool reduce = MODE != 0 && n_contrib > 1;
     // Bias and residual are fetched NOW, before the transpose: their latency runs under the two
@@ -327,8 +337,12 @@ void conv_gemm_kernel(ConvGemmDev p) {
     lds_barrier();
     if (reduce) {
       float *mine = slab_of(own);
-      for (int row = row0; row < BM; row += RSTEP)
+      for (int row = row0; row < BM; row += RSTEP) {
         *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
+        if (SPLIT)
+          *reinterpret_cast<float4 *>(mine + row * BN + BNO + 4 * col4) =
+              *reinterpret_cast<const float4 *>(Cs + row * LDC + BNO + 4 * col4);
+      }
       int &s_ticket = *reinterpret_cast<int *>(lds + LDS_MAIN);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -349,16 +363,26 @@ void conv_gemm_kernel(ConvGemmDev p) {
     // rows per step: NROW independent loads in flight instead of one (the row-by-row form made a
     // batch-1 split-K launch wait for NROW x n_contrib L2 round trips in sequence).
     floatx4 vsum[NROW];  // (an ext-vector type: arrays of the float4 struct spill)
+    floatx4 vlo[SPLIT ? NROW : 1];
     if (reduce) {
 #pragma unroll
       for (int i = 0; i < NROW; ++i) vsum[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) vlo[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      }
       for (int j = 0; j < n_contrib; ++j) {
         const float *src = j == own ? Cs + 4 * col4 : slab_of(j) + 4 * col4;
         const int ld = j == own ? LDC : BN;
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
           vsum[i] += *reinterpret_cast<const floatx4 *>(src + (row0 + i * RSTEP) * ld);
+          if (SPLIT) vlo[i] += *reinterpret_cast<const floatx4 *>(src + (row0 + i * RSTEP) * ld + BNO);
         }
+      }
+      if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) vsum[i] += vlo[i] * kLoScale;
       }
     }
 #pragma unroll
@@ -371,6 +395,10 @@ void conv_gemm_kernel(ConvGemmDev p) {
         v = make_float4(vsum[i][0], vsum[i][1], vsum[i][2], vsum[i][3]);
       } else {
         v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
+        if (SPLIT) {
+          const float4 lo = *reinterpret_cast<const float4 *>(Cs + row * LDC + BNO + 4 * col4);
+          v.x += lo.x * kLoScale; v.y += lo.y * kLoScale; v.z += lo.z * kLoScale; v.w += lo.w * kLoScale;
+        }
       }
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
       if (RES != 0) {
@@ -448,10 +476,10 @@ void conv_gemm_kernel(ConvGemmDev p) {
 int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = auto, 1 = 4 waves, 2 = 8 waves,
                          // 3 = no split-K, 4 = 64-wide tiles only, 6 = no stream-K tail
 
-template <typename T, int BN, int WM, int WN, int KS, int MODE>
+template <typename T, int BN, int WM, int WN, int KS, int MODE, bool SPLIT = false>
 int launch_cfg(const ConvGemmDev &d, int blocks, bool relu, int res, hipStream_t s) {
   const dim3 grid(blocks), block(64 * WM * WN);
-#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, MODE>), grid, block, 0, s, d)
+#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, MODE, SPLIT>), grid, block, 0, s, d)
   if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
@@ -465,11 +493,21 @@ int launch_cfg(const ConvGemmDev &d, int blocks, bool relu, int res, hipStream_t
   return check_launch("conv_gemm_kernel");
 }
 
-template <typename T, int KS>
+template <typename T, int KS, bool SPLIT = false>
 int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hipStream_t s) {
   const int tiles = d.mtiles * d.ntiles;
   d.tile_begin = 0;
   d.tile_count = tiles;
+  if (SPLIT) {  // always 128-wide: a tile is [hi | lo] of one 64-channel group
+    if (d.ksplit > 1) return launch_cfg<T, 128, 2, 4, KS, 1, SPLIT>(d, tiles * d.ksplit, relu, res, s);
+    if (streamk_tail > 0) {
+      d.tile_begin = tiles - streamk_tail;
+      d.tile_count = streamk_tail;
+      return launch_cfg<T, 128, 2, 4, KS, 2, SPLIT>(d, d.tile_begin + kResident, relu, res, s);
+    }
+    if (tiles <= 512) return launch_cfg<T, 128, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s);
+    return launch_cfg<T, 128, 2, 4, KS, 0, SPLIT>(d, tiles, relu, res, s);
+  }
   if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
     return launch_cfg<T, 64, 2, 2, KS, 1>(d, tiles * d.ksplit, relu, res, s);
   if (wide && streamk_tail > 0) {
@@ -520,13 +558,16 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide -- except that a
   // launch of 256..511 wide tiles (230 measured: no gain) with a long K loop runs wide as ONE stream-K round (block 4 at
   // batch 16, 720p: 460 wide tiles, or 920 narrow ones = 1.8 rounds, both 90 % full otherwise).
-  const long tiles128 = p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
+  const bool split = p.wsplit != 0;
+  DVSG_REQUIRE(!split || p.prec == kF16, "conv_gemm: split (hi + lo) weights are a float16 layout");
+  // split weights: 128 physical weight rows per 64 output channels, always one 128-wide tile each
+  const long tiles128 = split ? (long)d.mtiles * (p.Cout / 64) : p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
   const int kt_all = d.K / bke;
   const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
   const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes;
   const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
-  const bool wide = g_conv_variant != 4 && (tiles128 >= kResident || streamk_all);
-  d.ntiles = p.Cout / (wide ? 128 : 64);
+  const bool wide = split || (g_conv_variant != 4 && (tiles128 >= kResident || streamk_all));
+  d.ntiles = split ? p.Cout / 64 : p.Cout / (wide ? 128 : 64);
   // Tile order.  Each XCD runs a contiguous range of tiles.  With nt fastest that range covers every
   // weight panel, which is right while a panel (BN x K) is small; block 4's 3x3 conv has 2.4 MB
   // panels, and its stream-K workgroups stream them at 512 different K phases, so each tile fetched
@@ -541,9 +582,9 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
   // (measured at batch 1, 720p: pays for <= 128 tiles and K rows of >= 4 KiB, i.e. the 3x3 convs of
   // blocks 3-4 and block 4's 1x1 convs; shorter K loops lose more to the reduction than they gain)
-  if (g_conv_variant != 3 && p.splitk_scratch && !wide && tiles <= 128 && kt_all >= 32) {
+  if (g_conv_variant != 3 && p.splitk_scratch && (!wide || split) && tiles <= 128 && kt_all >= 32) {
     const int ks = (int)std::min<long>(8, std::min<long>(kResident / tiles, kt_all / 2));
-    const size_t need = (size_t)tiles * ks * BM * 64 * sizeof(float);
+    const size_t need = (size_t)tiles * ks * BM * (split ? 128 : 64) * sizeof(float);
     if (ks > 1 && need <= p.splitk_scratch_bytes && tiles <= kSplitKMaxTiles) d.ksplit = ks;
   }
   // Stream-K tail for the big 128-wide launches: only when the last round is clearly under-filled,
@@ -567,6 +608,9 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   if (p.prec == kF32)
     return p.ksize == 1 ? launch_ks<float, 1>(d, wide, streamk_tail, p.relu != 0, res, s)
                         : launch_ks<float, 3>(d, wide, streamk_tail, p.relu != 0, res, s);
+  if (split)
+    return p.ksize == 1 ? launch_ks<_Float16, 1, true>(d, wide, streamk_tail, p.relu != 0, res, s)
+                        : launch_ks<_Float16, 3, true>(d, wide, streamk_tail, p.relu != 0, res, s);
   return p.ksize == 1 ? launch_ks<_Float16, 1>(d, wide, streamk_tail, p.relu != 0, res, s)
                       : launch_ks<_Float16, 3>(d, wide, streamk_tail, p.relu != 0, res, s);
 }

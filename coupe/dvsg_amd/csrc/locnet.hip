@@ -32,8 +32,11 @@ struct ConvLayer {
   bool relu;
   float *wt = nullptr;        // device, [cout][k*k*cin] float32 (conv1: [7][64][kConv1Ld])
   _Float16 *wt16 = nullptr;   // device, same layout in float16 (not for conv1)
+  _Float16 *wt16s = nullptr;  // device, float16 hi / lo pairs [cout/64][128][k*k*cin] (conv_gemm.hip SPLIT; not for conv1)
   float *bias = nullptr;      // device, [cout] float32
-  const void *weights(int prec) const { return prec == kF16 ? (const void *)wt16 : (const void *)wt; }
+  const void *weights(int prec, bool split) const {
+    return prec == kF16 ? (split ? (const void *)wt16s : (const void *)wt16) : (const void *)wt;
+  }
 };
 
 struct Unit {
@@ -130,8 +133,21 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
     for (int n = 0; n < L->cout; ++n) wt[(size_t)n * K + k] = w->data[(size_t)k * L->cout + n] * scale[n];
   std::vector<_Float16> wt16(wt.size());
   for (size_t i = 0; i < wt.size(); ++i) wt16[i] = (_Float16)wt[i];
+  // hi / lo pairs: w ~ hi + 2^-11 lo, both float16 (a float16 weight alone is off by up to 2^-12 relative,
+  // the same way at every pixel); group g of 64 channels = rows [128 g, 128 g + 64) hi, then 64 rows lo
+  std::vector<_Float16> wt16s(2 * wt.size());
+  for (int n = 0; n < L->cout; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float w32 = wt[(size_t)n * K + k];
+      const _Float16 hi = (_Float16)w32;
+      const _Float16 lo = (_Float16)((w32 - (float)hi) * 2048.0f);
+      const size_t row = (size_t)(n / 64) * 128 + n % 64;
+      wt16s[row * K + k] = hi;
+      wt16s[(row + 64) * K + k] = lo;
+    }
   if (int rc = upload(net, wt, &L->wt)) return rc;
   if (int rc = upload(net, wt16, &L->wt16)) return rc;
+  if (int rc = upload(net, wt16s, &L->wt16s)) return rc;
   return upload(net, shift, &L->bias);
 }
 
@@ -180,6 +196,10 @@ Dims root_dims(int H, int W) {
 }
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// float16 precision: conv weights as hi / lo float16 pairs (default) or plain float16 (A/B only:
+// dvsg_debug_set_option("f16_split", 0); 9/10 of the plain mode's F_t error is the weights' rounding)
+int g_f16_split = 1;
 
 struct Workspace {
   char *bufA, *bufB, *bufS, *r1, *r2;  // activations (element type = the run's precision)
@@ -242,7 +262,8 @@ int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, v
   p.splitk_scratch_bytes = kSplitKSlabBytes;
   p.splitk_counters = ws.splitk_counters + (size_t)((*launch_idx)++ % kMaxConvLaunches) * kSplitKMaxTiles;
   p.prec = prec;
-  p.x = x; p.wt = L.weights(prec); p.bias = L.bias; p.res = res; p.y = y;
+  p.wsplit = prec == kF16 && g_f16_split;
+  p.x = x; p.wt = L.weights(prec, p.wsplit != 0); p.bias = L.bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
   p.res_H = res_H; p.res_W = res_W; p.res_stride = res_stride;
@@ -370,14 +391,15 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
   return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
 }
 
-int conv_gemm_op(int prec, const void *x, const void *wt, const float *bias, const void *res, void *y, int B, int H,
-                 int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const float *bias, const void *res, void *y, int B,
+                 int H, int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
                  size_t scratch_bytes, void *stream) {
   DVSG_REQUIRE(x && wt && bias && y, "dvsg_conv_gemm: NULL pointer");
   DVSG_REQUIRE(!scratch || ((uintptr_t)scratch & 255) == 0, "dvsg_conv_gemm: scratch must be 256-byte aligned");
   DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && res_stride >= 1, "dvsg_conv_gemm: bad shape");
   ConvGemm p;
   p.prec = prec;
+  p.wsplit = wsplit;
   p.x = x; p.wt = wt; p.bias = bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
@@ -537,14 +559,21 @@ int dvsg_locnet_forward_tap_f16(const dvsg_locnet_t *net, const float *patches, 
 int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const float *res, float *y, int B, int H,
                        int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
                        size_t scratch_bytes, void *stream) {
-  return conv_gemm_op(kF32, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+  return conv_gemm_op(kF32, 0, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
                       scratch_bytes, stream);
 }
 
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y, int B, int H,
                        int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
                        size_t scratch_bytes, void *stream) {
-  return conv_gemm_op(kF16, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+  return conv_gemm_op(kF16, 0, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+                      scratch_bytes, stream);
+}
+
+int dvsg_conv_gemm_f16s(const void *x, const void *wt_split, const float *bias, const void *res, void *y, int B, int H,
+                        int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+                        size_t scratch_bytes, void *stream) {
+  return conv_gemm_op(kF16, 1, x, wt_split, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
                       scratch_bytes, stream);
 }
 
@@ -575,6 +604,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "fuse_conv") == 0) {
     set_fuse_conv(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "f16_split") == 0) {
+    g_f16_split = value != 0;
     return DVSG_OK;
   }
   return fail(DVSG_ERR_INVALID_ARG, "dvsg_debug_set_option: unknown option %s", name);

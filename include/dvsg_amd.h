@@ -178,8 +178,10 @@ int dvsg_conv_gemm_f32(const float *x, const float *wt, const float *bias, const
  * float16 variants (BASELINE.json configs[4]: "fp16 MFMA convs").  Same arguments and the same
  * float32 inputs / outputs as the _f32 entry points; inside, activations and conv weights are
  * stored as float16 and the 1x1 / 3x3 convolutions run on v_mfma_f32_32x32x16_f16 with float32
- * accumulation (conv1 multiplies the float32 frames in f32 and writes f16; BatchNorm shift,
- * the dense head, the TPS solve and the warp stay float32).  Not bit-compatible with the
+ * accumulation, their weights kept as float16 hi / lo pairs (see dvsg_conv_gemm_f16s: a plain float16
+ * weight is off by up to 2^-12 relative at EVERY pixel alike, which the global average pool does not
+ * average away -- it was 9/10 of this mode's error in F_t); conv1 multiplies float16 copies of the
+ * scaled frames and writes f16; BatchNorm shift, the dense head, the TPS solve and the warp stay float32.  Not bit-compatible with the
  * float32 reference path: tests/test_gpu_f16.py states the measured F_t / pixel error.
  * The workspace of dvsg_locnet_workspace_bytes is sufficient (half of it is used).
  * ------------------------------------------------------------------------------------- */
@@ -196,6 +198,13 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                        int res_stride, void *scratch, size_t scratch_bytes, void *stream);
+/* The layer as the float16 network runs it: float16 activations against weights kept as float16
+ * hi / lo PAIRS, w ~ hi + 2^-11 lo (hi = f16(w), lo = f16((w - hi) * 2048)), i.e. effectively float32
+ * weights at twice the matrix-core work and unchanged activation traffic.  wt_split is
+ * [Cout/64][128][K]: for each group of 64 output channels 64 rows of hi, then 64 rows of lo. */
+int dvsg_conv_gemm_f16s(const void *x, const void *wt_split, const float *bias, const void *res, void *y,
+                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                        int res_stride, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Data formats either side of the path (the reference's eval.py driver, which keeps frames in
@@ -237,7 +246,7 @@ int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, c
                          const float *res, float *y, int B, int H, int W, int Cin, int Cout, int stride, int res_stride,
                          void *stream);
 
-/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant", "fuse_conv").  Process-global. */
+/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant", "fuse_conv", "f16_split").  Process-global. */
 int dvsg_debug_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------

@@ -141,8 +141,8 @@ def test_cfg3_one_rank_shard_of_64_windows(dev, synthetic_weights):
 def test_cfg4_b32_4k_f16(dev, synthetic_weights):
     """configs[4]: B=32 3840x2160 windows in ONE `dvsg_stabilize_f16` call (22 GB of windows and a
     ~60 GB workspace fit the 288 GB of HBM: no sub-batching).  float16 storage cannot be bit-compatible
-    with the float32 reference; stated bounds against the float32 CPU oracle at this size:
-    F_t < 2e-3 (|F_t| ~ 0.1).  Exact properties: bitwise run-to-run determinism, batch invariance up to
+    with the float32 reference; stated bound against the float32 CPU oracle at this size:
+    F_t < 1e-5 (|F_t| ~ 0.1; float16 activations, hi / lo float16 weight pairs -- tests/test_gpu_f16.py).  Exact properties: bitwise run-to-run determinism, batch invariance up to
     accumulation order, and the identity map of the (float32) 4K TPS stage."""
     import torch
     from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
@@ -172,7 +172,7 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
     for b in (0, 21):
         rF = ref.forward(x[b:b + 1].cpu().numpy())
         err = np.abs(F[b:b + 1].cpu().numpy() - rF).max()
-        assert err < 2e-3, "window %d: f16 F_t error %.3g" % (b, err)
+        assert err < 1e-5, "window %d: f16 F_t error %.3g" % (b, err)
     del out, o1
     # the warp stage of configs[4] (float32 in both modes) at 4K: zero control vectors -> identity grid
     coord = torch.from_numpy(inputs.v_src(2)).to(dev)

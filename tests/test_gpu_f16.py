@@ -1,7 +1,13 @@
 """GPU: the float16 variant of localizationNet (BASELINE.json configs[4] "fp16 MFMA convs").
 float16 storage cannot be bit-compatible with the float32 reference; this file STATES the measured
 error against the float32 oracle (tolerances are ~3x the values observed on MI355X) and checks the
-properties that must still hold exactly."""
+properties that must still hold exactly.
+
+The float16 mode keeps ACTIVATIONS in float16 and the conv weights as float16 hi / lo pairs
+(w ~ hi + 2^-11 lo, two MFMAs per product): a plain float16 weight is wrong by up to 2^-12 relative
+in the same way at every pixel, an error the global average pool cannot average away -- it was 9/10
+of the mode's F_t error (2.0e-5 at 720p, warped pixels 1.5e-3).  With the pairs: F_t 1.7e-6, source
+grid 3e-3 px, warped pixels 3.9e-4 at 720p, the same as the float32 path end to end."""
 import numpy as np
 import pytest
 
@@ -31,11 +37,11 @@ def test_f16_stages_track_the_f32_oracle(net, synthetic_weights, B, H, W):
         ref = taps[name]
         assert act.shape == ref.shape
         rel = np.abs(act - ref).max() / np.abs(ref).max()
-        # float16 has an 11-bit significand: ~5e-4 per rounding, accumulated over up to 50 layers
-        assert rel < 2e-2, "%s: relative error %.3g" % (name, rel)
+        # float16 has an 11-bit significand: ~5e-4 per rounding of an activation, over up to 50 layers
+        assert rel < 1e-2, "%s: relative error %.3g" % (name, rel)
     F = net.forward(x, precision="f16").cpu().numpy()
     err = np.abs(F - F_ref).max()
-    assert err < 2e-3, "F_t error %.3g (|F| ~ %.3g)" % (err, np.abs(F_ref).max())
+    assert err < 5e-5, "F_t error %.3g (|F| ~ %.3g)" % (err, np.abs(F_ref).max())
     F32 = net.forward(x, precision="f32").cpu().numpy()
     assert np.abs(F32 - F_ref).max() <= 1e-5          # the f32 path is untouched by the f16 weights
 
@@ -59,14 +65,50 @@ def test_f16_stabilize_and_determinism(net, synthetic_weights):
     gerr = max(np.abs(xs - rx).max() * W / 2, np.abs(ys - ry).max() * H / 2)
     mask = border_discontinuity_mask(rx, ry, H, W, delta=0.2).reshape(B, H, W)
     perr = np.abs(got - ref).max(axis=3)[~mask].max()
-    # stated values for the float16 path (float32 path: < 2e-2 px, < 3e-3)
-    assert gerr < 0.2, "grid error %.3g px" % gerr
-    assert perr < 3e-2, "pixel error %.3g" % perr
+    # stated values for the float16 path on these small frames (float32 path: < 2e-2 px, < 3e-3)
+    assert gerr < 5e-2, "grid error %.3g px" % gerr
+    assert perr < 6e-3, "pixel error %.3g" % perr
+
+
+def test_f16_meets_the_pixel_tolerance_at_720p(synthetic_weights):
+    """BASELINE.json's tolerance (warped-frame max abs error < 1e-3) for the float16 mode at 1280x720,
+    two windows end to end against the float32 CPU oracle: F_t < 1e-5 (measured 1.7e-6), source grid
+    < 2e-2 px (3e-3), pixels < 1e-3 (3.9e-4) outside the counted sampler-A border-discontinuity pixels.
+    With plain float16 weights (dvsg_debug_set_option("f16_split", 0)) the same numbers are 2.0e-5,
+    9.7e-3 px and 1.5e-3: the hi / lo weight pairs are what closes the gap."""
+    from coupe.dvsg_amd import _lib
+    from coupe.dvsg_amd.model import Session, StabNet
+    from oracle import thin_plate_spline as otps
+    from oracle.cnn_torch import TorchLocNet
+    B, H, W = 2, 720, 1280
+    x = inputs.window_frames(7, B, H, W)
+    u = np.ascontiguousarray(x[..., 18:])
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    model.precision = "f16"
+    ins, outs = model.get_evaluation_model(7)
+    fetch = [outs["s_t_pred"], outs["F_t"], outs["x_offset_t"], outs["y_offset_t"]]
+    pred, F, xs, ys = Session().run(fetch, {ins["patches_t"]: x, ins["u_t"]: u})
+    F_ref = TorchLocNet(synthetic_weights).forward(x)
+    r_pred, r_xs, r_ys = otps.ThinPlateSpline(u, inputs.v_src(B), F_ref, (H, W))
+    border = otps.border_discontinuity_mask(r_xs, r_ys, H, W, delta=3e-2).reshape(B, H, W)
+    ferr = np.abs(F - F_ref).max()
+    gerr = max(np.abs(xs - r_xs).max() * W / 2, np.abs(ys - r_ys).max() * H / 2)
+    perr = np.abs(pred - r_pred).max(axis=3)[~border].max()
+    print("f16 (hi/lo weights) at 720p: F_t %.2e, grid %.2e px, pixels %.2e" % (ferr, gerr, perr))
+    assert ferr < 1e-5 and gerr < 2e-2 and perr < 1e-3 and border.mean() < 0.01
+    _lib.call("dvsg_debug_set_option", b"f16_split", 0)
+    try:
+        F_plain = Session().run(outs["F_t"], {ins["patches_t"]: x, ins["u_t"]: u})
+    finally:
+        _lib.call("dvsg_debug_set_option", b"f16_split", 1)
+    assert np.abs(F_plain - F_ref).max() > 3 * ferr          # plain float16 weights are what it costs
 
 
 def test_conv_gemm_f16_layer(net):
     """One 3x3 and one 1x1 layer through dvsg_conv_gemm_f16 against float32 math on the same
-    (float16-rounded) operands: only the float32 accumulation order differs."""
+    (float16-rounded) operands: only the float32 accumulation order differs.  Then the same layers
+    with float32 weights given as hi / lo float16 pairs (dvsg_conv_gemm_f16s) against float32 math on
+    the UNROUNDED weights, small batch (split-K) and large (plain tiles, stream-K tail)."""
     import torch
     from coupe.dvsg_amd import _lib
     dev = torch.device("cuda:0")
@@ -87,3 +129,26 @@ def test_conv_gemm_f16_layer(net):
         ref = torch.relu(ref.permute(0, 2, 3, 1) + res.float())
         err = float((y.float() - ref).abs().max())
         assert err < 4e-3 * max(1.0, float(ref.abs().max())), (k, stride, cin, err)
+        # hi / lo pairs of float32 weights
+        w32 = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
+        hi = w32.half()
+        lo = ((w32 - hi.float()) * 2048.0).half()
+        ws = torch.stack([hi.reshape(cout // 64, 64, K), lo.reshape(cout // 64, 64, K)], 1).reshape(2 * cout, K).contiguous()
+        scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+        for Bs in (2, 40):
+            xs = (torch.rand((Bs, h, w, cin), generator=g, device=dev) - 0.3).half()
+            rs = (torch.rand((Bs, ho, wo, cout), generator=g, device=dev) - 0.5).half()
+            ys = torch.empty((Bs, ho, wo, cout), device=dev, dtype=torch.float16)
+            _lib.call("dvsg_conv_gemm_f16s", xs.data_ptr(), ws.data_ptr(), bias.data_ptr(), rs.data_ptr(), ys.data_ptr(),
+                      Bs, h, w, cin, cout, k, stride, 1, 1, scratch.data_ptr(), scratch.numel(),
+                      torch.cuda.current_stream().cuda_stream)
+            w4 = w32.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(xs.float().permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2)
+            ref = torch.relu(ref.permute(0, 2, 3, 1) + rs.float())
+            # what is left is the float16 rounding of the OUTPUT (2^-11 relative) and summation order
+            err = float((ys.float() - ref).abs().max())
+            assert err < 1.2e-3 * max(1.0, float(ref.abs().max())), (k, stride, cin, Bs, err)
+            y16 = torch.empty_like(ys)   # against plain float16 weights the pairs must be clearly closer in the mean
+            _lib.call("dvsg_conv_gemm_f16", xs.data_ptr(), w32.half().contiguous().data_ptr(), bias.data_ptr(), rs.data_ptr(),
+                      y16.data_ptr(), Bs, h, w, cin, cout, k, stride, 1, 1, 0, 0, torch.cuda.current_stream().cuda_stream)
+            assert float((ys.float() - ref).abs().mean()) <= float((y16.float() - ref).abs().mean())
