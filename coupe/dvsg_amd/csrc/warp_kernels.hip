@@ -22,19 +22,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxPts = 61;  // P + 3 <= 64
 
-// Natural log of a NORMAL, finite, positive float (here d^2 + 1e-6 in [1e-6, ~32]): the same
-// arithmetic as the device library's logf -- v_log_f32 (log2) times ln2 carried as a hi/lo pair
-// with the product's rounding error compensated -- minus its denormal pre-scaling and inf/NaN
-// selects, which such arguments never take.  Same results, 5 instructions instead of 9: the
-// TPS grid evaluates 25 logs per output pixel and is VALU-bound on them.
-__device__ __forceinline__ float log_normal_pos(float x) {
-  const float y = __builtin_amdgcn_logf(x);
-  const float c = 0x1.62e42ep-1f, cc = 0x1.efa39ep-25f;
-  const float hgh = y * c;
-  const float t = fmaf(y, cc, fmaf(y, c, -hgh));
-  return hgh + t;
-}
-
 // ----------------------------------------------------------------------------------------
 // TPS system solve: ThinPlateSpline.py:143-166.  One wave per batch sample, thread = row of
 // the (P+3)x(P+3) system, Gauss-Jordan with partial pivoting in float64 on the float32-built
@@ -367,27 +354,24 @@ constexpr int kMaxGenericC = 64;
 // ----------------------------------------------------------------------------------------
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
-// log_normal_pos on a pair of values: the same operations, two rows per v_pk_* instruction.
-__device__ __forceinline__ floatx2 log_normal_pos2(floatx2 x) {
-  floatx2 y;
-  y.x = __builtin_amdgcn_logf(x.x);
-  y.y = __builtin_amdgcn_logf(x.y);
-  const floatx2 c = {0x1.62e42ep-1f, 0x1.62e42ep-1f}, cc = {0x1.efa39ep-25f, 0x1.efa39ep-25f};
-  const floatx2 hgh = y * c;
-  const floatx2 t = __builtin_elementwise_fma(y, cc, __builtin_elementwise_fma(y, c, -hgh));
-  return hgh + t;
-}
-
 // The 25 basis terms per pixel make this kernel VALU-bound, so the inner loop is written for the
-// packed-float32 pipe: every add / mul of the reference graph is one v_pk_add_f32 / v_pk_mul_f32
-// over a PAIR of rows (same IEEE roundings as the scalar ops, so the results do not change), and
-// (y_t - py)^2 -- the same for every column of a row -- is computed once per workgroup and read
-// back as a broadcast ds_read_b128.
-// A thread owns one column and 4 rows (two pairs).  Measured at B=16, 720p: basis 98 us (42 cycles
-// per control point, row and wave: 11 packed ops + 2 v_log_f32 per pair) + sampling 60-80 us (the
-// same 4.5 TB/s the other bilinear samplers reach); a variant with 8 rows per thread that issued one
+// packed-float32 pipe -- one v_pk_* instruction per PAIR of rows -- and kept to 5 packed ops + 2
+// v_log_f32 per control point and pair:
+//   * (y_t - py)^2 -- the same for every column of a row -- is computed once per workgroup and read
+//     back as a broadcast ds_read_b128; (x_t - px)^2 is shared by the thread's rows;
+//   * r = d2 ln(d2 + 1e-6) enters the map only through T . r, so the ln 2 of ln = ln 2 x log2 is
+//     folded into the two T entries of the control point when they are staged in LDS, and the loop
+//     uses v_log_f32 (log2, 1 ulp) as it stands -- no product by a hi / lo ln 2 per term;
+//   * T . basis accumulates with fused multiply-adds.  The reference's T @ grid is a GEMM (Eigen:
+//     blocked, FMA where the CPU has it), so no summation order or rounding of it is pinned; the k
+//     order of the oracle is kept.
+// Against the previous form (device-library ln, separately rounded mul / add: 11 packed ops + 2 logs)
+// the source grid moves by < 1e-3 px at 720p, inside the float32 evaluation noise of the map itself
+// (3e-3 px against the oracle either way); tests/test_gpu_warps.py bounds grid and pixel error.
+// A thread owns one column and 4 rows (two pairs); a variant with 8 rows per thread that issued one
 // group's tap loads under the other group's basis loop was no faster, so the simple form stays.
 constexpr int kTpsRows = 4;
+constexpr float kLn2 = 0x1.62e43p-1f;
 
 template <int C>
 __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
@@ -404,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
   const int i0 = blockIdx.y * kTpsRows;
   if (t < P) {
     const float px = coord[b * coord_bstride + t * 2], py = coord[b * coord_bstride + t * 2 + 1];
-    sp[t] = make_float4(px, py, T[((size_t)b * 2) * n + 3 + t], T[((size_t)b * 2 + 1) * n + 3 + t]);
+    sp[t] = make_float4(px, py, T[((size_t)b * 2) * n + 3 + t] * kLn2, T[((size_t)b * 2 + 1) * n + 3 + t] * kLn2);
     float dy2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -440,10 +424,12 @@ __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const floatx2 dyy = h == 0 ? floatx2{q.x, q.y} : floatx2{q.z, q.w};
-      const floatx2 d2 = dxx + dyy;                                          // :104
-      const floatx2 rk = d2 * log_normal_pos2(d2 + floatx2{1e-6f, 1e-6f});   // :105
-      xs2[h] = xs2[h] + c.z * rk;
-      ys2[h] = ys2[h] + c.w * rk;
+      const floatx2 d2 = dxx + dyy;                        // :104
+      const floatx2 e = d2 + floatx2{1e-6f, 1e-6f};
+      const floatx2 l2 = {__builtin_amdgcn_logf(e.x), __builtin_amdgcn_logf(e.y)};
+      const floatx2 rk = d2 * l2;                          // :105 up to the factor ln 2 carried by c.z / c.w
+      xs2[h] = __builtin_elementwise_fma(floatx2{c.z, c.z}, rk, xs2[h]);
+      ys2[h] = __builtin_elementwise_fma(floatx2{c.w, c.w}, rk, ys2[h]);
     }
   }
   const float xs[4] = {xs2[0].x, xs2[0].y, xs2[1].x, xs2[1].y};
