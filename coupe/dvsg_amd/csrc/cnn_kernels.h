@@ -46,11 +46,17 @@ struct ConvFused {
   const float *bias2;  // [64]
   const float *wt3;    // [Cout][64]
   const float *bias3;  // [Cout]
-  const float *res;    // [B,res_H,res_W,Cout], sampled at (ho*res_stride, wo*res_stride)
+  const float *res;    // [B,res_H,res_W,Cout], sampled at (ho*res_stride, wo*res_stride); NULL with sc_x
   float *y;            // [B,Ho,Wo,Cout]
   int B, H, W, Cin, Ho, Wo, Cout;
   int stride;
   int res_H, res_W, res_stride;
+  // the unit that opens a block: residual = 1x1 `shortcut` conv (+ BN) of the unit's input, computed in the
+  // kernel from sc_x [B,Ho,Wo,sc_cin] (stride 1), sc_wt [Cout][sc_cin], sc_bias [Cout]; the tensor never exists
+  const float *sc_x = nullptr;
+  const float *sc_wt = nullptr;
+  const float *sc_bias = nullptr;
+  int sc_cin = 0;
 };
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize);
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s);

@@ -10,6 +10,12 @@
 // 720p) never exists, and conv3's residual loads / output stores run under conv2's matrix-core time
 // of the other workgroup on the CU.
 //
+// RES == 3 (the unit that opens the block, whose residual is itself a convolution, the 1x1 `shortcut`
+// of the unit's input): phase 0 computes that convolution for the tile -- the input tile and the
+// shortcut weights go through the still empty LDS -- straight into phase 2's accumulators, which
+// conv3 then continues.  The [M,256] shortcut tensor (944 MB written and read back per step at batch
+// 16, 720p) and its launch disappear; phase 0 costs what conv3 costs.
+//
 // Phase 1 is conv_gemm_kernel's 64-wide configuration unchanged (8 waves = 4 x 2 tiles of 32 x 32,
 // LDS-DMA staging, XOR-swizzled K-contiguous rows, two stages, channel chunk outer / taps inner).
 // Phase 2 keeps the 128 x 64 tile in the first 32 KiB of LDS as two 32-k stages and streams conv3's
@@ -35,7 +41,9 @@ struct ConvFusedDev {
   const float *bias2;  // [64]
   const float *wt3;    // conv3 [Cout][64]
   const float *bias3;  // [Cout]
-  const float *res;    // residual [B,res_H,res_W,Cout]
+  const float *res;    // residual [B,res_H,res_W,Cout]; RES == 3: the unit's input [M,Csc] (shortcut's operand)
+  const float *wts;    // RES == 3: shortcut weights [Cout][Csc]
+  const float *biass;  // RES == 3: shortcut bias [Cout]
   float *y;            // [B,Ho,Wo,Cout]
   int H, W, Cin, Ho, Wo, Cout;
   int stride;
@@ -43,7 +51,9 @@ struct ConvFusedDev {
   int M, mtiles;
 };
 
-template <int RES>  // 1: residual has the output's shape, 2: subsampled shortcut x[:, ::s, ::s, :]
+constexpr int CSC = 64;     // RES == 3: channels of the shortcut's input (block 1: the pooled conv1 output)
+
+template <int RES>  // 1: residual has the output's shape, 2: subsampled shortcut x[:, ::s, ::s, :], 3: shortcut conv fused
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void conv3x3_1x1_kernel(ConvFusedDev p) {
   constexpr int NW = 8;
@@ -64,6 +74,70 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
   typedef __attribute__((address_space(3))) void *lptr_t;
 
   const int m0 = xcd_remap(blockIdx.x, p.mtiles) * BM;
+
+  // ---------------------------------------------------------------- phase 0 (RES == 3): shortcut conv of the tile
+  // acc_sc[half][ni]: the 128 x 256 shortcut tile in phase 2's accumulator layout (wave tile 32 x 64 per
+  // 128-channel half).  LDS: input tile as two 32-k stages at 0 / 16 KiB, shortcut weights (128 rows x 32 k
+  // = 16 KiB per (half, stage) piece) alternating between 32 KiB and 48 KiB.
+  floatx16 acc_sc[RES == 3 ? 2 : 1][2];
+  if (RES == 3) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc_sc[hf][ni][q] = 0.f;
+    auto xs_issue = [&](int s2) __attribute__((always_inline)) {   // rows of the unit's input: dense [M, CSC]
+#pragma unroll
+      for (int i = 0; i < AG; ++i) {
+        const int row = 8 * (wave + NW * i) + lrow8;
+        const int m = m0 + row < p.M ? m0 + row : p.M - 1;
+        const float *src = p.res + (size_t)m * CSC + 32 * s2 + 4 * (lpos ^ ((row >> 1) & 7));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + s2 * 16384 + 8 * (wave + NW * i) * ROWB), 16, 0, 0);
+      }
+    };
+    auto ws_issue = [&](int step) __attribute__((always_inline)) {  // step = 2 half + stage -> buffer step & 1
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + NW * i) + lrow8;
+        const float *src = p.wts + (size_t)(128 * (step >> 1) + row) * CSC + 32 * (step & 1) + 4 * (lpos ^ ((row >> 1) & 7));
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + 32768 + (step & 1) * 16384 + 8 * (wave + NW * i) * ROWB),
+                                         16, 0, 0);
+      }
+    };
+    xs_issue(0);
+    ws_issue(0);
+    xs_issue(1);
+    ws_issue(1);
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      // pieces land in issue order: all but the youngest two (the next step's) have landed
+      if (step == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (step == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char *a_base = lds + (step & 1) * 16384 + (wm * 32 + r) * ROWB;
+      const char *b_base = lds + 32768 + (step & 1) * 16384 + (wn * 64 + r) * ROWB;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int co = 16 * ((2 * kb + h) ^ sw);
+        const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_base + co);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_base + ni * 32 * ROWB + co);
+          acc_sc[step >> 1][ni] = Frag<float>::mma(a4, b4, acc_sc[step >> 1][ni]);
+        }
+      }
+      if (step < 2) {  // the buffer just read takes the piece two steps ahead
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ws_issue(step + 2);
+      }
+    }
+    __syncthreads();  // phase 1 restages all of LDS
+  }
 
   // ---------------------------------------------------------------- phase 1: conv2 tile 128 x 64
   long a_off[AG];
@@ -194,13 +268,9 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
       }
     }
   };
+  // one 128-channel half of the output: conv3 on top of `acc2` (zeros, or the half's shortcut tile)
   const int nhalves = p.Cout / 128;
-  for (int half = 0; half < nhalves; ++half) {
-    floatx16 acc2[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc2[ni][q] = 0.f;
+  auto do_half = [&](int half, floatx16 (&acc2)[2]) __attribute__((always_inline)) {
     // weight stage 0 has landed once at most stage 1's two DMA instructions are outstanding
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // (first half: the conv2 tile written above is visible too)
@@ -210,26 +280,32 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
     compute2(1, acc2);
     // epilogue of this half: two rounds of 64 rows through the (now idle) weight area
     const int n = 128 * half + 4 * col4;
-    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias3 + n);
+    float4 bias4 = *reinterpret_cast<const float4 *>(p.bias3 + n);
+    if (RES == 3) {
+      const float4 bs = *reinterpret_cast<const float4 *>(p.biass + n);
+      bias4.x += bs.x; bias4.y += bs.y; bias4.z += bs.z; bias4.w += bs.w;
+    }
 #pragma unroll
     for (int rho = 0; rho < 2; ++rho) {
       // residual of this round's rows is fetched before the transpose (its latency runs under it)
       float4 rv[4];
+      if (RES != 3) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int mr = m0 + 64 * rho + row0 + 16 * i;
-        const int m = mr < p.M ? mr : p.M - 1;
-        size_t roff;
-        if (RES == 1) {
-          roff = (size_t)m * p.Cout + n;
-        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
-          const int wo = m % p.Wo;
-          const int t = m / p.Wo;
-          const int ho = t % p.Ho;
-          const int b = t / p.Ho;
-          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        for (int i = 0; i < 4; ++i) {
+          const int mr = m0 + 64 * rho + row0 + 16 * i;
+          const int m = mr < p.M ? mr : p.M - 1;
+          size_t roff;
+          if (RES == 1) {
+            roff = (size_t)m * p.Cout + n;
+          } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+            const int wo = m % p.Wo;
+            const int t = m / p.Wo;
+            const int ho = t % p.Ho;
+            const int b = t / p.Ho;
+            roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+          }
+          rv[i] = load4(p.res + roff);
         }
-        rv[i] = load4(p.res + roff);
       }
       lds_barrier();  // weights of this half consumed / previous round's rows read
       if ((wm >> 1) == rho) {
@@ -246,10 +322,17 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
         const int m = m0 + 64 * rho + row;
         if (m < p.M) {
           float4 v = *reinterpret_cast<const float4 *>(Cs + row * 128 + 4 * col4);
-          v.x = fmaxf(v.x + bias4.x + rv[i].x, 0.f);
-          v.y = fmaxf(v.y + bias4.y + rv[i].y, 0.f);
-          v.z = fmaxf(v.z + bias4.z + rv[i].z, 0.f);
-          v.w = fmaxf(v.w + bias4.w + rv[i].w, 0.f);
+          if (RES == 3) {  // the shortcut is already in the accumulators; its bias in bias4
+            v.x = fmaxf(v.x + bias4.x, 0.f);
+            v.y = fmaxf(v.y + bias4.y, 0.f);
+            v.z = fmaxf(v.z + bias4.z, 0.f);
+            v.w = fmaxf(v.w + bias4.w, 0.f);
+          } else {
+            v.x = fmaxf(v.x + bias4.x + rv[i].x, 0.f);
+            v.y = fmaxf(v.y + bias4.y + rv[i].y, 0.f);
+            v.z = fmaxf(v.z + bias4.z + rv[i].z, 0.f);
+            v.w = fmaxf(v.w + bias4.w + rv[i].w, 0.f);
+          }
           store4(p.y + (size_t)m * p.Cout + n, v);
         }
       }
@@ -258,6 +341,19 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
       lds_barrier();  // the transpose buffer has been read: the next 128 weight rows may land in it
       w3_issue(half + 1, 0);
       w3_issue(half + 1, 1);
+    }
+  };
+  if (RES == 3) {  // exactly two halves (launch_conv3x3_1x1 checks Cout == 256): static accumulator indices
+    do_half(0, acc_sc[0]);
+    do_half(1, acc_sc[1]);
+  } else {
+    for (int half = 0; half < nhalves; ++half) {
+      floatx16 acc2[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc2[ni][q] = 0.f;
+      do_half(half, acc2);
     }
   }
 }
@@ -274,25 +370,33 @@ bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize) {
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
   DVSG_REQUIRE(p.Cin % 32 == 0 && p.Cin >= 64 && p.Cout % 128 == 0, "conv3x3_1x1: Cin=%d must be a multiple of 32 (>= 64), Cout=%d of 128",
                p.Cin, p.Cout);
-  DVSG_REQUIRE(p.res, "conv3x3_1x1: the unit output needs its residual");
+  const bool sc = p.sc_x != nullptr;  // the residual is the 1x1 shortcut conv of sc_x, computed in the kernel
+  DVSG_REQUIRE(p.res || sc, "conv3x3_1x1: the unit output needs its residual");
+  DVSG_REQUIRE(!sc || (p.sc_wt && p.sc_bias && p.sc_cin == CSC && p.Cout == 256 && p.stride == 1),
+               "conv3x3_1x1: fused shortcut needs %d input channels, 256 output channels and stride 1 (got %d, %d, %d)",
+               CSC, p.sc_cin, p.Cout, p.stride);
   const long M = (long)p.B * p.Ho * p.Wo;
   DVSG_REQUIRE(M > 0 && M < (1L << 31) - BM, "conv3x3_1x1: M=%ld out of range", M);
   ConvFusedDev d;
-  d.x = p.x; d.wt2 = p.wt2; d.bias2 = p.bias2; d.wt3 = p.wt3; d.bias3 = p.bias3; d.res = p.res; d.y = p.y;
+  d.x = p.x; d.wt2 = p.wt2; d.bias2 = p.bias2; d.wt3 = p.wt3; d.bias3 = p.bias3; d.y = p.y;
+  d.res = sc ? p.sc_x : p.res; d.wts = p.sc_wt; d.biass = p.sc_bias;
   d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
   d.stride = p.stride;
   d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;
   d.M = (int)M;
   d.mtiles = (int)((M + BM - 1) / BM);
-  const int res = p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2;
-  // algorithmic work: both contractions; bytes = input + both weight sets + residual + output, once each
-  ProfScope prof(kClsFused, s, 2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID,
+  const int res = sc ? 3 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
+  // algorithmic work: the contractions; bytes = input + weight sets + residual (or the shortcut's input) + output, once each
+  ProfScope prof(kClsFused, s,
+                 2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID + (sc ? 2.0 * (double)M * p.Cout * CSC : 0.0),
                  4.0 * ((double)p.B * p.H * p.W * p.Cin + (double)CMID * 9 * p.Cin + (double)p.Cout * CMID +
-                        2.0 * (double)M * p.Cout));
+                        (sc ? (double)M * CSC + (double)p.Cout * CSC + (double)M * p.Cout : 2.0 * (double)M * p.Cout)));
   if (res == 1)
     hipLaunchKernelGGL(conv3x3_1x1_kernel<1>, dim3(d.mtiles), dim3(512), 0, s, d);
-  else
+  else if (res == 2)
     hipLaunchKernelGGL(conv3x3_1x1_kernel<2>, dim3(d.mtiles), dim3(512), 0, s, d);
+  else
+    hipLaunchKernelGGL(conv3x3_1x1_kernel<3>, dim3(d.mtiles), dim3(512), 0, s, d);
   return check_launch("conv3x3_1x1_kernel");
 }
 

@@ -128,6 +128,14 @@ void conv_gemm_kernel(ConvGemmDev p) {
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
   typedef typename Frag<T>::type frag_t;
+#ifdef DVSG_STAMPS  // diagnostic build (tools/stamp_probe.py): per-workgroup phase times, mode 0 only
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  st[0] = __builtin_amdgcn_s_memtime();
+  st[6] = __builtin_amdgcn_s_memrealtime();
+#define DVSG_STAMP(i) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define DVSG_STAMP(i)
+#endif
 
   // One (tile, K-stage range) segment.  `n_contrib` contributors share the tile; this one is
   // number `own` (in K order), its partial goes to slab `slab_of(own)`, the tile's ticket is
@@ -261,6 +269,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
     // orders everyone's reads of the buffer about to be refilled.
     const int KT = kt1 - kt0;
     constexpr int PER = AG + BG;  // LDS-DMA instructions per wave and stage
+    DVSG_STAMP(1);
     issue_stage(0);
     if (KT > 1) {
       issue_stage(1);
@@ -270,11 +279,22 @@ void conv_gemm_kernel(ConvGemmDev p) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    DVSG_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     compute_stage(0);
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 1; kt < KT - 1; ++kt) {
+#ifdef DVSG_STAMPS
+      const unsigned long long b0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long b1 = __builtin_amdgcn_s_memtime();
       __syncthreads();
+      const unsigned long long b2 = __builtin_amdgcn_s_memtime();
+      st[5] += b1 - b0;   // own DMA not landed yet
+      st[7] += b2 - b1;   // waiting for the other waves
+#else
+      __syncthreads();
+#endif
       issue_stage((kt + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       compute_stage(kt & 1);
@@ -285,6 +305,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       compute_stage((KT - 1) & 1);
     }
 
+    DVSG_STAMP(3);
     // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
     constexpr int LDC = BN + 4;
     constexpr int BNO = SPLIT ? BN / 2 : BN;  // output channels of the tile
@@ -430,6 +451,19 @@ void conv_gemm_kernel(ConvGemmDev p) {
   if (MODE == 0) {
     const int tile = p.tile_begin + xcd_remap(blockIdx.x, p.tile_count);
     run_segment(tile, 0, KT_all, 1, 0, 0, [&](int) -> float * { return nullptr; });
+#ifdef DVSG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[4] = __builtin_amdgcn_s_memtime();
+    if (p.slabs && tid == 0) {
+      unsigned long long *o = reinterpret_cast<unsigned long long *>(p.slabs) + (size_t)blockIdx.x * 8;
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      o[0] = __builtin_amdgcn_s_memrealtime() - st[6]; o[1] = st[1] - st[0]; o[2] = st[2] - st[1]; o[3] = st[3] - st[2]; o[4] = st[4] - st[3];
+      o[5] = st[5]; o[6] = st[6]; o[7] = st[7] | ((unsigned long long)(xcc & 0xf) << 56) | ((unsigned long long)(hwid & 0xffff) << 40);
+    }
+#endif
   } else if (MODE == 1) {
     // the slices of one tile are adjacent logical ids (same XCD: the reducer reads its siblings'
     // slabs out of its own L2)

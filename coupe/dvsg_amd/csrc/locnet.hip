@@ -200,6 +200,8 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // float16 precision: conv weights as hi / lo float16 pairs (default) or plain float16 (A/B only:
 // dvsg_debug_set_option("f16_split", 0); 9/10 of the plain mode's F_t error is the weights' rounding)
 int g_f16_split = 1;
+// block 1's shortcut conv inside the fused conv2 + conv3 kernel (dvsg_debug_set_option("fuse_shortcut", 0): A/B)
+int g_fuse_shortcut = 1;
 
 struct Workspace {
   char *bufA, *bufB, *bufS, *r1, *r2;  // activations (element type = the run's precision)
@@ -325,18 +327,27 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
     const int ho = (h - 1) / u.stride + 1, wo = (w - 1) / u.stride + 1;
     const void *res = X;
     int res_h = h, res_w = w, res_stride = u.stride;
-    if (u.has_shortcut) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
+    const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize);
+    // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
+    const bool fuse_sc = fuse23 && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
+                         g_fuse_shortcut;
+    if (u.has_shortcut && !fuse_sc) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
       DVSG_RUN(run_conv(prec, u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws, &launch_idx, s));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
     }
     DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
-    if (conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize)) {  // block 1: conv2 + conv3 in one kernel
+    if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
       f.x = reinterpret_cast<const float *>(ws.r1); f.wt2 = u.c2.wt; f.bias2 = u.c2.bias; f.wt3 = u.c3.wt; f.bias3 = u.c3.bias;
       f.res = static_cast<const float *>(res); f.y = reinterpret_cast<float *>(Y);
       f.B = B; f.H = h; f.W = w; f.Cin = u.c2.cin; f.Ho = ho; f.Wo = wo; f.Cout = u.c3.cout;
       f.stride = u.c2.stride; f.res_H = res_h; f.res_W = res_w; f.res_stride = res_stride;
+      if (fuse_sc) {
+        f.res = nullptr;
+        f.sc_x = reinterpret_cast<const float *>(X); f.sc_wt = u.shortcut.wt; f.sc_bias = u.shortcut.bias;
+        f.sc_cin = u.shortcut.cin;
+      }
       DVSG_RUN(launch_conv3x3_1x1(f, s));
     } else {
       DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
@@ -604,6 +615,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "fuse_conv") == 0) {
     set_fuse_conv(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "fuse_shortcut") == 0) {
+    g_fuse_shortcut = value != 0;
     return DVSG_OK;
   }
   if (std::strcmp(name, "f16_split") == 0) {

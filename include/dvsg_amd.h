@@ -246,7 +246,7 @@ int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, c
                          const float *res, float *y, int B, int H, int W, int Cin, int Cout, int stride, int res_stride,
                          void *stream);
 
-/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant", "fuse_conv", "f16_split").  Process-global. */
+/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant", "fuse_conv", "fuse_shortcut", "f16_split").  Process-global. */
 int dvsg_debug_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------

@@ -33,7 +33,9 @@ template <int V>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void loop_kernel(float *out, int stages,
                                                                                                 unsigned seed,
                                                                                                 const float *src,
-                                                                                                long src_floats) {
+                                                                                                long src_floats,
+                                                                                                unsigned long long *stamps) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
@@ -202,43 +204,68 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float sum = 0.f;
   for (int q = 0; q < 16; ++q) sum += acc0[q] + acc1[q];
   out[blockIdx.x * 512 + tid] = sum;
+  if (tid == 0) {
+    stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+    stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+}
+
+__global__ void fill_random(float *p, long n, unsigned seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned s = seed ^ (unsigned)(i * 2654435761u) ^ (unsigned)(i >> 32);
+    s = s * 1664525u + 1013904223u;
+    s ^= s >> 15;
+    s *= 2246822519u;
+    s ^= s >> 13;
+    p[i] = (float)(int)(s >> 8) * (1.0f / 8388608.0f) - 1.0f;
+  }
 }
 
 int main() {
   float *out, *src;
+  unsigned long long *stamps;
+  hipMalloc(&stamps, 2 * 4096 * sizeof(unsigned long long));
   hipMalloc(&out, 512 * 4096 * sizeof(float));
   const long src_floats = 1L << 30;   // 4 GiB
   hipMalloc(&src, src_floats * sizeof(float));
-  hipMemset(src, 0x3c, src_floats * sizeof(float));
+  hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, src, src_floats, 7u);   // random operands: DVFS is data dependent
+  hipDeviceSynchronize();
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int stages = 4000;
+  const int stages = 20000;
   for (int rep = 0; rep < 2; ++rep)
-    for (int v = 0; v < 12; ++v)
+    for (int v : {0, 4, 5, 9})
       for (int blocks_per_cu : {1, 2}) {
         const int blocks = 256 * blocks_per_cu;
         float ms = 0;
         for (int r = 0; r < 2; ++r) {
           hipEventRecord(e0);
-          if (v == 0) hipLaunchKernelGGL(loop_kernel<0>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 1) hipLaunchKernelGGL(loop_kernel<1>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 2) hipLaunchKernelGGL(loop_kernel<2>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 3) hipLaunchKernelGGL(loop_kernel<3>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 4) hipLaunchKernelGGL(loop_kernel<4>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 5) hipLaunchKernelGGL(loop_kernel<5>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 6) hipLaunchKernelGGL(loop_kernel<6>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 7) hipLaunchKernelGGL(loop_kernel<7>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 8) hipLaunchKernelGGL(loop_kernel<8>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 9) hipLaunchKernelGGL(loop_kernel<9>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 10) hipLaunchKernelGGL(loop_kernel<10>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
-          if (v == 11) hipLaunchKernelGGL(loop_kernel<11>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats);
+          if (v == 0) hipLaunchKernelGGL(loop_kernel<0>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 1) hipLaunchKernelGGL(loop_kernel<1>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 2) hipLaunchKernelGGL(loop_kernel<2>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 3) hipLaunchKernelGGL(loop_kernel<3>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 4) hipLaunchKernelGGL(loop_kernel<4>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 5) hipLaunchKernelGGL(loop_kernel<5>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 6) hipLaunchKernelGGL(loop_kernel<6>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 7) hipLaunchKernelGGL(loop_kernel<7>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 8) hipLaunchKernelGGL(loop_kernel<8>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 9) hipLaunchKernelGGL(loop_kernel<9>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 10) hipLaunchKernelGGL(loop_kernel<10>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
+          if (v == 11) hipLaunchKernelGGL(loop_kernel<11>, dim3(blocks), dim3(512), 0, 0, out, stages, 1u, src, src_floats, stamps);
           hipEventRecord(e1);
           hipEventSynchronize(e1);
           hipEventElapsedTime(&ms, e0, e1);
         }
         const double flops = (double)blocks * 8 * stages * 32.0 * 4096.0;
-        printf("V%d  workgroups/CU=%d  %.2f ms  %.1f TFLOP/s\n", v, blocks_per_cu, ms, flops / ms / 1e9);
+        unsigned long long h[2 * 512];
+        hipMemcpy(h, stamps, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
+        double clk = 0;
+        for (int i = 0; i < blocks; ++i) clk += (double)h[2 * i] / (double)h[2 * i + 1] * 100.0;
+        printf("V%d  workgroups/CU=%d  %.2f ms  %.1f TFLOP/s  clock %.0f MHz  pipe busy %.3f\n", v, blocks_per_cu, ms, flops / ms / 1e9,
+               clk / blocks, (double)stages * 32 * 64 * 2 * blocks_per_cu / (double)h[0]);
       }
   return 0;
 }
