@@ -32,6 +32,11 @@ constexpr int C1_SEG_PAD = 5488;
 constexpr int C1_WELEMS = 64 * kConv1Ld;                      // 9600 floats per kernel row
 constexpr int C1_LDC = 68;                                    // epilogue tile row stride
 
+#ifdef DVSG_STAMPS  // diagnostic build (tools/stamp_probe_conv1.py): per-workgroup phase times of conv1_kernel
+__device__ unsigned long long g_c1_stamps[8 * 65536];
+#define C1_STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int NW, typename TO>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
 void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, const float *__restrict__ bias,
@@ -119,12 +124,35 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[mi][q] = 0.f;
 
+#ifdef DVSG_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = C1_STAMP(), r_begin = __builtin_amdgcn_s_memrealtime();
+#endif
   load_stage(0);
+#ifdef DVSG_STAMPS
+  st[0] = C1_STAMP() - t_begin;  // prologue (index setup) + first load issue
+#endif
   for (int kh = 0; kh < 7; ++kh) {
+#ifdef DVSG_STAMPS  // (each stamp drains lgkmcnt: the phase times below are upper bounds)
+    const unsigned long long s0 = C1_STAMP();
+    __syncthreads();
+    const unsigned long long s1 = C1_STAMP();
+    store_stage();
+    const unsigned long long s2 = C1_STAMP();
+    __syncthreads();
+    const unsigned long long s3 = C1_STAMP();
+    if (kh + 1 < 7) load_stage(kh + 1);
+    const unsigned long long s4 = C1_STAMP();
+    st[1] += s1 - s0;  // barrier 1 (+ vmcnt(0): the prefetched row and weights)
+    st[2] += s2 - s1;  // scale + LDS stores
+    st[3] += s3 - s2;  // barrier 2
+    st[4] += s4 - s3;  // issue of the next row's loads
+#else
     __syncthreads();  // everyone is done reading the previous kernel row
     store_stage();
     __syncthreads();
     if (kh + 1 < 7) load_stage(kh + 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
     const float *a0 = in_s + 2 * kConv1Cin * (wm * 32 * MI + r) + 2 * h;
     const float *bp = w_s + (wn * 32 + r) * kConv1Ld + 2 * h;
@@ -142,6 +170,9 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     }
   }
 
+#ifdef DVSG_STAMPS
+  const unsigned long long t_loop_end = C1_STAMP();
+#endif
   // ---- epilogue: transpose through the (idle) weight stage so stores are float4s along channels
   float *Cs = w_s;
   __syncthreads();
@@ -164,6 +195,16 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     v.w = fmaxf(v.w + b4.w, 0.f);
     store4(yrow + (size_t)row * 64, v);
   }
+#ifdef DVSG_STAMPS
+  if (tid == 0 && blockIdx.x < 65536) {
+    unsigned long long *o = g_c1_stamps + (size_t)blockIdx.x * 8;
+    const unsigned long long t_end = C1_STAMP();
+    o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3]; o[4] = st[4];
+    o[5] = t_loop_end - t_begin;            // up to the end of the last MFMA loop
+    o[6] = t_end - t_begin;                 // lifetime (stores issued, not necessarily landed)
+    o[7] = __builtin_amdgcn_s_memrealtime() - r_begin;
+  }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------
@@ -383,6 +424,12 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1
   }
   return check_launch("conv1_kernel");
 }
+
+#ifdef DVSG_STAMPS
+extern "C" int dvsg_debug_read_conv1_stamps(void *host, size_t bytes) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c1_stamps), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
                    int pad_left, hipStream_t s) {
