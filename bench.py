@@ -62,20 +62,24 @@ def gpu_windows(B, H, W, seed, dev, S=7):
 
 def pmc_traffic(cls, B, H, W, precision="f32"):
     """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes
-    (profiles/rNN_traffic.json, written by tools/summarize_profiles.py from separate FETCH_SIZE /
+    (profiles/rNN*_traffic.json, written by tools/summarize_profiles.py from separate FETCH_SIZE /
     WRITE_SIZE runs of this same command with the gfx950 corrections of MI355X_MICROARCH.md).
-    Counters cannot be read from inside the timed run, so this is the last profiled value; it is
-    only reported when the workload shape is the profiled one (B=16, 720p)."""
+    Counters cannot be read from inside the timed run, so this is the last profiled value of the SAME
+    workload (batch, size, precision recorded in the file); None for any other shape."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files or (B, H, W) != (16, 720, 1280) or precision != "f32":
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            c = json.load(f)["classes"].get(str(cls))
-        return (c["bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if c else (None, None)
-    except (OSError, ValueError, KeyError):
-        return None, None
+    want = {"batch": B, "height": H, "width": W, "precision": precision}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("workload", {"batch": 16, "height": 720, "width": 1280, "precision": "f32"}) != want:
+                continue
+            c = d["classes"].get(str(cls))
+            if c:
+                return c["bytes_per_launch"], os.path.relpath(path, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def usable_cores():

@@ -14,7 +14,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-CLASSES = {"conv1_kernel": 0, "conv_gemm": None, "maxpool_kernel": 3, "tps_solve_kernel": 5, "tps_warp_kernel": 6,
+CLASSES = {"conv1_kernel": 0, "conv1_f16_kernel": 0, "conv_gemm": None, "maxpool_kernel": 3, "tps_solve_kernel": 5, "tps_warp_kernel": 6,
            "stn_kernel": 7, "dense_kernel": 4, "avgpool_partial_kernel": 4, "dense_finalize_kernel": 4}
 
 
@@ -25,6 +25,13 @@ def short(n):
 
 def kclass(name):
     s = short(name)
+    m = re.search(r"_GLOBAL__N_1\d+(\w+?)I", s)   # rocprofv3 leaves _Float16 instantiations mangled
+    if s.startswith("_ZN") and m:
+        base = m.group(1)
+        if base == "conv_gemm_kernel":
+            li = re.findall(r"Li(\d+)E", s)      # <T, BN, WM, WN, KS, ...>
+            return 1 if len(li) >= 4 and li[3] == "3" else 2
+        s = base
     if s.startswith("conv3x3_1x1_kernel"):   # block 1's fused conv2 + conv3
         return 8
     if s.startswith("conv_gemm"):
@@ -67,7 +74,16 @@ def write_pmc(d, path):
     return per, disp
 
 
-def main(src, dst, tag):
+def workload_of(flags):
+    """The profiled bench.py workload (batch, height, width, precision) from its command-line flags."""
+    import shlex
+    a = shlex.split(flags or "")
+    get = lambda k, d: a[a.index(k) + 1] if k in a else d
+    return {"batch": int(get("--batch", 16)), "height": int(get("--height", 720)), "width": int(get("--width", 1280)),
+            "precision": get("--precision", "f32")}
+
+
+def main(src, dst, tag, flags=""):
     stats = newest(src + "/stats/**/*_kernel_stats.csv")
     shutil.copy(stats, "%s/%s_kernel_stats.csv" % (dst, tag))
     write_pmc(src + "/pmc_sq", "%s/%s_pmc_sq.csv" % (dst, tag))
@@ -83,10 +99,11 @@ def main(src, dst, tag):
             traffic[str(cls)] = {"fetch_bytes_per_launch": fb / fn, "write_bytes_per_launch": wb / wn,
                                  "bytes_per_launch": fb / fn + wb / wn, "launches_profiled": fn}
     json.dump({"note": "FETCH_SIZE x1024 x2 (gfx950 half-count correction) + WRITE_SIZE x1024, separate --pmc passes; "
-                       "memory-side (fabric) requests, Infinity-Cache hits included", "classes": traffic},
+                       "memory-side (fabric) requests, Infinity-Cache hits included",
+               "workload": workload_of(flags), "classes": traffic},
               open("%s/%s_traffic.json" % (dst, tag), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
