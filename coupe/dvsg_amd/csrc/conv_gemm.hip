@@ -269,12 +269,55 @@ void conv_gemm_kernel(ConvGemmDev p) {
     // orders everyone's reads of the buffer about to be refilled.
     const int KT = kt1 - kt0;
     constexpr int PER = AG + BG;  // LDS-DMA instructions per wave and stage
+    // ---- epilogue geometry (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
+    constexpr int LDC = BN + 4;
+    constexpr int BNO = SPLIT ? BN / 2 : BN;  // output channels of the tile
+    constexpr int C4 = BNO / 4;      // 4-channel groups per output row
+    constexpr int RSTEP = NT / C4;   // tile rows covered per pass
+    constexpr int NROW = BM / RSTEP; // rows per thread
+    constexpr float kLoScale = 1.0f / 2048.0f;
+    const int col4 = tid % C4, row0 = tid / C4;
+    const int n = (SPLIT ? nt * BNO : n0) + 4 * col4;
+    const bool reduce = MODE != 0 && n_contrib > 1;
+    // The residual of a plain tile is fetched right behind the first two stages' DMA (EARLY_RES): its
+    // HBM round trip and its share of the layer's traffic run under the main loop instead of in front of
+    // the epilogue -- a K = 128 layer with a residual moves 4 bytes of residual and output per byte of
+    // input.  (Other tiles fetch it before the epilogue's transpose, where its latency still runs under
+    // the two barriers and the LDS round trip.)  Rows past M read row M-1: unconditional loads, the
+    // store is what is guarded.
+    constexpr bool EARLY_RES = RES != 0 && MODE == 0 && sizeof(T) == 4 && NROW <= 8;
+    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+    float4 rv[NROW];
+    auto load_residual = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NROW; ++i) {
+        const int mr = m0 + row0 + i * RSTEP;
+        const int m = mr < p.M ? mr : p.M - 1;
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(pres + roff);
+      }
+    };
     DVSG_STAMP(1);
     issue_stage(0);
     if (KT > 1) {
       issue_stage(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      if (EARLY_RES) {
+        load_residual();  // NROW more loads behind the DMA of stage 1: stage 0 has landed once PER + NROW are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + (EARLY_RES ? NROW : 0)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      }
     } else {
+      if (EARLY_RES) load_residual();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -306,41 +349,9 @@ void conv_gemm_kernel(ConvGemmDev p) {
     }
 
     DVSG_STAMP(3);
-    // ---- epilogue (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
-    constexpr int LDC = BN + 4;
-    constexpr int BNO = SPLIT ? BN / 2 : BN;  // output channels of the tile
-    constexpr int C4 = BNO / 4;      // 4-channel groups per output row
-    constexpr int RSTEP = NT / C4;   // tile rows covered per pass
-    constexpr int NROW = BM / RSTEP; // rows per thread
-    constexpr float kLoScale = 1.0f / 2048.0f;
-    const int col4 = tid % C4, row0 = tid / C4;
-    const int n = (SPLIT ? nt * BNO : n0) + 4 * col4;
+    // ---- epilogue
     float *Cs = reinterpret_cast<float *>(lds);
-    const bool reduce = MODE != 0 && n_contrib > 1;
-    // Bias and residual are fetched NOW, before the transpose: their latency runs under the two
-    // barriers and the LDS round trip (the barriers below wait for LDS traffic only, not vmcnt;
-    // loading the residual inside the store loop exposed two L2 / HBM round trips per tile).
-    // Rows past M read row M-1: unconditional loads, the store is what is guarded.
-    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
-    float4 rv[NROW];
-    if (RES != 0 && !reduce) {
-#pragma unroll
-      for (int i = 0; i < NROW; ++i) {
-        const int mr = m0 + row0 + i * RSTEP;
-        const int m = mr < p.M ? mr : p.M - 1;
-        size_t roff;
-        if (RES == 1) {
-          roff = (size_t)m * p.Cout + n;
-        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
-          const int wo = m % p.Wo;
-          const int t = m / p.Wo;
-          const int ho = t % p.Ho;
-          const int b = t / p.Ho;
-          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
-        }
-        rv[i] = load4(pres + roff);
-      }
-    }
+    if (RES != 0 && !reduce && !EARLY_RES) load_residual();
     auto lds_barrier = [&]() __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -514,7 +525,14 @@ template <typename T, int BN, int WM, int WN, int KS, int MODE, bool SPLIT = fal
 int launch_cfg(const ConvGemmDev &d, int blocks, bool relu, int res, hipStream_t s) {
   const dim3 grid(blocks), block(64 * WM * WN);
 #define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_gemm_kernel<T, BN, WM, WN, KS, R, Q, MODE, SPLIT>), grid, block, 0, s, d)
-  if (relu) {
+  if constexpr (MODE == 2) {
+    // stream-K launches never carry a residual (launch_conv_gemm): with one, the finisher's partial sums
+    // and residual rows together do not fit the 128-VGPR budget of 4 waves per SIMD (8-13 spills), and
+    // no layer of resnet_v1_50 needs it (a residual layer's K is the unit's narrow width)
+    if (res != 0) return fail(DVSG_ERR_UNSUPPORTED, "conv_gemm: stream-K launch with a residual");
+    if (relu) DVSG_LAUNCH(true, 0);
+    else DVSG_LAUNCH(false, 0);
+  } else if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
     else DVSG_LAUNCH(true, 2);
@@ -598,7 +616,7 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   const long tiles128 = split ? (long)d.mtiles * (p.Cout / 64) : p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
   const int kt_all = d.K / bke;
   const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
-  const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes;
+  const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes && res == 0;
   const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
   const bool wide = split || (g_conv_variant != 4 && (tiles128 >= kResident || streamk_all));
   d.ntiles = split ? p.Cout / 64 : p.Cout / (wide ? 128 : 64);
