@@ -26,6 +26,11 @@
 // stores (and residual loads) per MFMA block per lane; instead the accumulators are transposed
 // through the idle staging LDS so every thread moves 4 consecutive channels (float4 / 4 x f16).
 //
+// (Measured again in round 2 with sustained clocks, tools/conv_bench.py --variants 0,7: a resident grid
+// of 512 / 768 workgroups that walk the tiles at a static stride, nothing else changed, is 1.3 % slower
+// over the 52 launches of a step -- +2 % on the K = 64 layers, -2..-17 % on the others: workgroup
+// turnover is not what small-K tiles lose, and a static assignment gives up the dispatcher's balancing.)
+//
 // (Measured and rejected alternatives to this epilogue, batch 16 at 720p: storing straight from the
 // accumulators -- 16 dword stores per block, or, with the MFMA operands swapped so a lane holds 4
 // consecutive channels of one pixel, 4 x 16-byte stores of 32 bytes per pixel per instruction --

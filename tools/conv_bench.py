@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", default="uniq")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--rep", type=int, default=20,
+                    help="back-to-back launches per timing (1 = isolated launches: the clock governor has not ramped "
+                         "and short kernels read 10-15 %% low, DESIGN.md 5.0)")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     dev = torch.device("cuda:0")
@@ -83,11 +86,12 @@ def main():
                 _lib.call("dvsg_debug_set_option", b"conv_variant", v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                run()
+                for _ in range(args.rep):
+                    run()
                 e1.record()
                 e1.synchronize()
                 if rnd > 0:
-                    times[v].append(e0.elapsed_time(e1) * 1e3)
+                    times[v].append(e0.elapsed_time(e1) * 1e3 / args.rep)
         cells = []
         for v in variants:
             us = float(np.median(times[v]))

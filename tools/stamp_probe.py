@@ -32,7 +32,8 @@ for arg in sys.argv[1:]:
         e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3
     M = B * H * W
-    tiles = -(-M // 128) * (cout // 128)
+    mt = -(-M // 128)
+    tiles = mt * (cout // 128) if cout % 128 == 0 and mt * (cout // 128) >= 512 else mt * (cout // 64)
     st = scratch[2048:2048 + tiles * 64].view(torch.int64).reshape(tiles, 8).cpu().numpy().astype(np.uint64)
     t0 = st[:, 0].astype(np.float64)
     rt = st[:, 6].astype(np.float64) / 100.0       # us
