@@ -29,7 +29,9 @@
 // (Measured again in round 2 with sustained clocks, tools/conv_bench.py --variants 0,7: a resident grid
 // of 512 / 768 workgroups that walk the tiles at a static stride, nothing else changed, is 1.3 % slower
 // over the 52 launches of a step -- +2 % on the K = 64 layers, -2..-17 % on the others: workgroup
-// turnover is not what small-K tiles lose, and a static assignment gives up the dispatcher's balancing.)
+// turnover is not what small-K tiles lose, and a static assignment gives up the dispatcher's balancing.
+// Four fat waves (64 x 64 wave tiles: a third fewer fragment reads per MFMA) in every mode, stream-K
+// included: 17.83 vs 17.76 ms, i.e. nothing -- LDS read volume is not a lever either.)
 //
 // (Measured and rejected alternatives to this epilogue, batch 16 at 720p: storing straight from the
 // accumulators -- 16 dword stores per block, or, with the MFMA operands swapped so a lane holds 4
