@@ -244,8 +244,10 @@ def main():
                     help="kernel class timed for the roofline object (default: 1 = 3x3 convs, or 7 for tf_warp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"],
-                    help="f32 (default, the reference's arithmetic: the headline number) or f16 activations/weights")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f16"],
+                    help="f32 (default, the reference's arithmetic: the headline number); f32s: float32 storage / "
+                         "accumulation with products from two float16 pieces per operand (dtype f32x2f16); f16: float16 "
+                         "activations, hi / lo float16 weight pairs")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the batch of one step is split over (LocNet.stabilize); 2 is <1 %% faster "
                          "but concurrent launches make the per-kernel hipEvent durations of `roofline` meaningless")
@@ -376,7 +378,9 @@ def main():
         cls = args.prof_class
         if cls in MFMA_CLASSES:
             achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" or cls == 0 else PEAK_F16_MFMA_TFLOPS
+            # f32s: three float16 MFMAs per float32-equivalent product; f16: two (hi / lo weights), priced on algorithmic FLOPs
+            peak = (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" or cls == 0 else
+                    PEAK_F16_MFMA_TFLOPS / 3.0 if args.precision == "f32s" else PEAK_F16_MFMA_TFLOPS)
             roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
         else:
             achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
@@ -404,7 +408,8 @@ def main():
             "metric": ("tf_warp frames/sec (%dx%d RGB)" if flow_mode else "stabilized frames/sec (%dx%d RGB)") % (W, H),
             "value": frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if flow_mode else args.precision,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if flow_mode else {"f32s": "f32x2f16"}.get(args.precision, args.precision),
             "data": "synthetic",
             "config": {"workload": ("%s: batch=%d %dx%d frames, optical-flow warp (warp_with_optical_flow.tf_warp) per GPU"
                                     if flow_mode else

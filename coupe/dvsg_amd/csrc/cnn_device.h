@@ -48,6 +48,27 @@ struct Frag<_Float16> {
   }
 };
 
+// "f32s" products: eight float32 values (two 16-byte chunks, consecutive k) -> their float16 pieces
+// hi = rtz_f16(x) and lo = f16(x - hi).  x - hi is exact in float32 (hi is x truncated to 11 significant
+// bits), so hi + lo carries 22 significant bits of x; lo may be a float16 subnormal, which the matrix
+// cores keep.  4 v_cvt_pkrtz + 8 v_cvt_f32_f16 + 8 subtractions + 4 v_cvt_pkrtz per 8 values.
+__device__ __forceinline__ void split_f16x2(floatx4 f0, floatx4 f1, halfx8 &hi, halfx8 &lo) {
+  typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+  const float f[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(f[2 * i], f[2 * i + 1]);
+    const halfx2 h2 = __builtin_bit_cast(halfx2, hp);
+    hi[2 * i] = h2[0];
+    hi[2 * i + 1] = h2[1];
+    const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(f[2 * i] - (float)h2[0], f[2 * i + 1] - (float)h2[1]);
+    const halfx2 l2 = __builtin_bit_cast(halfx2, lp);
+    lo[2 * i] = l2[0];
+    lo[2 * i + 1] = l2[1];
+  }
+}
+
 // Four consecutive channels of an activation tensor <-> float4.
 __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 load4(const _Float16 *p) {

@@ -11,7 +11,10 @@
 
 namespace dvsg {
 
-enum Precision { kF32 = 0, kF16 = 1 };
+// kF32S: float32 storage and accumulation like kF32, but the 1x1 / 3x3 convolutions form their products
+// on the float16 matrix cores from two float16 pieces per operand (22 significant bits; conv_gemm.hip).
+// Everything that is not a conv_gemm launch treats it as kF32.
+enum Precision { kF32 = 0, kF16 = 1, kF32S = 2 };
 inline size_t elem_size(int prec) { return prec == kF16 ? 2 : 4; }
 
 // Implicit-GEMM convolution (1x1 or 3x3, NHWC, C_in % 64 == 0 (f16) / 32 (f32), C_out % 64 == 0):
@@ -28,7 +31,8 @@ struct ConvGemm {
   int ksize, stride, pad;
   int res_H, res_W, res_stride;
   int relu;
-  int wsplit = 0;     // kF16 only: wt is the split layout [Cout/64][128][K] (64 hi rows, then 64 lo rows; conv_gemm.hip)
+  int wsplit = 0;     // kF16: wt is the stacked layout [Cout/64][128][K] (64 hi rows, then 64 lo rows); kF32: wt is
+                      // [Cout][K/32][32 hi halves | 32 lo halves] and products are formed from float16 pieces (conv_gemm.hip)
   // optional split-K scratch (small batches): partial-tile slabs and kSplitKMaxTiles zeroed int tickets
   void *splitk_scratch = nullptr;
   size_t splitk_scratch_bytes = 0;

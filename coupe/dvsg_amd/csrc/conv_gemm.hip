@@ -92,17 +92,31 @@ struct ConvGemmDev {
   int mt_fast;     // tile order, see run_segment
 };
 
-// SPLIT (float16 only): the weight matrix holds, for every group of 64 output channels, 128 rows -- the
-// float16 weights of the group (hi) followed by their rounding residuals (w - hi) x 2^11, again float16
-// (lo).  A 128-wide tile is then [hi | lo] of ONE 64-channel group and the epilogue folds it to 64
-// output channels, hi + 2^-11 lo: float16 activations against effectively float32 weights.  (A float16
-// weight carries a FIXED relative error of up to 2^-12 that is the same at every pixel, so it survives
-// the global average pool; it was 9/10 of the float16 mode's error in F_t.  The scale keeps lo a
-// normal float16 whatever the matrix cores do with subnormal inputs.)
+// SPLIT, T = _Float16 ("f16" precision): the weight matrix holds, for every group of 64 output channels,
+// 128 rows -- the float16 weights of the group (hi) followed by their rounding residuals (w - hi) x 2^11,
+// again float16 (lo).  A 128-wide tile is then [hi | lo] of ONE 64-channel group and the epilogue folds it
+// to 64 output channels, hi + 2^-11 lo: float16 activations against effectively float32 weights.  (A
+// float16 weight carries a FIXED relative error of up to 2^-12 that is the same at every pixel, so it
+// survives the global average pool; it was 9/10 of the float16 mode's error in F_t.  The scale keeps lo a
+// normal float16.)
+//
+// SPLIT, T = float ("f32s" precision): float32 storage everywhere, float32 accumulation, but every
+// PRODUCT is formed on the float16 matrix cores from two float16 pieces per operand, x ~ x1 + x2 with
+// x1 = rtz_f16(x), x2 = f16(x - x1): 22 significant bits.  a w ~ a1 w1 + a2 w1 + a1 w2 (the dropped a2 w2
+// is 2^-22 relative), each float16 product exact in float32 -- three v_mfma_f32_32x32x16_f16 (96 cycles)
+// where the exact path issues eight v_mfma_f32_32x32x2_f32 (512 cycles).  Activations are split in
+// registers right after the fragment read (~24 VALU per 8 values, under the other waves' MFMAs), weights
+// once at load: a weight row stage is 128 bytes like a float32 one -- 32 hi halves, then 32 lo halves --
+// so tiles, LDS-DMA and swizzle are the float32 kernel's, byte for byte.  float16 subnormals are inputs
+// the matrix cores keep (tools/f16_subnormal_probe.hip), so nothing is scaled.  Against the exact path:
+// stage activations within 2e-6 relative, F_t within 1e-7 (a CPU emulation of the arithmetic and the GPU
+// tests agree), i.e. at the level at which two float32 GEMMs with different summation orders differ.
 template <typename T, int BN, int WM, int WN, int KS, bool RELU, int RES, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN / 2, WM * WN / 2)))
 void conv_gemm_kernel(ConvGemmDev p) {
-  static_assert(!SPLIT || (sizeof(T) == 2 && BN == 128), "split weights: float16, 128-wide tiles");
+  constexpr bool WSTACK = SPLIT && sizeof(T) == 2;  // f16: [hi | lo] weight rows stacked along N
+  constexpr bool PSPLIT = SPLIT && sizeof(T) == 4;  // f32s: products from float16 pieces
+  static_assert(!WSTACK || BN == 128, "stacked hi / lo weights: 128-wide tiles");
   constexpr int NW = WM * WN;
   constexpr int NT = 64 * NW;
   constexpr int MI = BM / WM / 32;          // 32-row MFMA blocks per wave
@@ -253,6 +267,33 @@ void conv_gemm_kernel(ConvGemmDev p) {
     auto compute_stage = [&](int buf) __attribute__((always_inline)) {
       const char *a_base = As + (buf * BM + wm * (BM / WM) + r) * ROWB;
       const char *b_base = Bs + (buf * BN + wn * (BN / WN) + r) * ROWB;
+      if constexpr (PSPLIT) {
+        // two 16-k MFMA steps per 32-k stage; lane half h owns the k-run of 8 number g = 2 t + h:
+        // activations = float32 chunks 2g, 2g+1 of the row, weights = half chunk g (hi) and 4 + g (lo)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int g = 2 * t + h;
+          halfx8 ahi[MI], alo[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const floatx4 f0 = *reinterpret_cast<const floatx4 *>(a_base + mi * 32 * ROWB + 16 * ((2 * g) ^ sw));
+            const floatx4 f1 = *reinterpret_cast<const floatx4 *>(a_base + mi * 32 * ROWB + 16 * ((2 * g + 1) ^ sw));
+            split_f16x2(f0, f1, ahi[mi], alo[mi]);
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const halfx8 bhi = *reinterpret_cast<const halfx8 *>(b_base + ni * 32 * ROWB + 16 * (g ^ sw));
+            const halfx8 blo = *reinterpret_cast<const halfx8 *>(b_base + ni * 32 * ROWB + 16 * ((4 + g) ^ sw));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi, acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi, acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo, acc[mi][ni], 0, 0, 0);
+            }
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         const int co = 16 * ((2 * kb + h) ^ sw);
@@ -278,13 +319,13 @@ void conv_gemm_kernel(ConvGemmDev p) {
     constexpr int PER = AG + BG;  // LDS-DMA instructions per wave and stage
     // ---- epilogue geometry (C/D map of the 32x32 MFMA: col = lane & 31, row = (q&3) + 8 (q>>2) + 4 h)
     constexpr int LDC = BN + 4;
-    constexpr int BNO = SPLIT ? BN / 2 : BN;  // output channels of the tile
+    constexpr int BNO = WSTACK ? BN / 2 : BN;  // output channels of the tile
     constexpr int C4 = BNO / 4;      // 4-channel groups per output row
     constexpr int RSTEP = NT / C4;   // tile rows covered per pass
     constexpr int NROW = BM / RSTEP; // rows per thread
     constexpr float kLoScale = 1.0f / 2048.0f;
     const int col4 = tid % C4, row0 = tid / C4;
-    const int n = (SPLIT ? nt * BNO : n0) + 4 * col4;
+    const int n = (WSTACK ? nt * BNO : n0) + 4 * col4;
     const bool reduce = MODE != 0 && n_contrib > 1;
     // The residual of a plain tile is fetched right behind the first two stages' DMA (EARLY_RES): its
     // HBM round trip and its share of the layer's traffic run under the main loop instead of in front of
@@ -292,7 +333,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
     // input.  (Other tiles fetch it before the epilogue's transpose, where its latency still runs under
     // the two barriers and the LDS round trip.)  Rows past M read row M-1: unconditional loads, the
     // store is what is guarded.
-    constexpr bool EARLY_RES = RES != 0 && MODE == 0 && sizeof(T) == 4 && NROW <= 8;
+    constexpr bool EARLY_RES = RES != 0 && MODE == 0 && sizeof(T) == 4 && !PSPLIT && NROW <= 8;
     const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
     float4 rv[NROW];
     auto load_residual = [&]() __attribute__((always_inline)) {
@@ -378,7 +419,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       float *mine = slab_of(own);
       for (int row = row0; row < BM; row += RSTEP) {
         *reinterpret_cast<float4 *>(mine + row * BN + 4 * col4) = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
-        if (SPLIT)
+        if (WSTACK)
           *reinterpret_cast<float4 *>(mine + row * BN + BNO + 4 * col4) =
               *reinterpret_cast<const float4 *>(Cs + row * LDC + BNO + 4 * col4);
       }
@@ -402,11 +443,11 @@ void conv_gemm_kernel(ConvGemmDev p) {
     // rows per step: NROW independent loads in flight instead of one (the row-by-row form made a
     // batch-1 split-K launch wait for NROW x n_contrib L2 round trips in sequence).
     floatx4 vsum[NROW];  // (an ext-vector type: arrays of the float4 struct spill)
-    floatx4 vlo[SPLIT ? NROW : 1];
+    floatx4 vlo[WSTACK ? NROW : 1];
     if (reduce) {
 #pragma unroll
       for (int i = 0; i < NROW; ++i) vsum[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (SPLIT) {
+      if (WSTACK) {
 #pragma unroll
         for (int i = 0; i < NROW; ++i) vlo[i] = floatx4{0.f, 0.f, 0.f, 0.f};
       }
@@ -416,10 +457,10 @@ void conv_gemm_kernel(ConvGemmDev p) {
 #pragma unroll
         for (int i = 0; i < NROW; ++i) {
           vsum[i] += *reinterpret_cast<const floatx4 *>(src + (row0 + i * RSTEP) * ld);
-          if (SPLIT) vlo[i] += *reinterpret_cast<const floatx4 *>(src + (row0 + i * RSTEP) * ld + BNO);
+          if (WSTACK) vlo[i] += *reinterpret_cast<const floatx4 *>(src + (row0 + i * RSTEP) * ld + BNO);
         }
       }
-      if (SPLIT) {
+      if (WSTACK) {
 #pragma unroll
         for (int i = 0; i < NROW; ++i) vsum[i] += vlo[i] * kLoScale;
       }
@@ -434,7 +475,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
         v = make_float4(vsum[i][0], vsum[i][1], vsum[i][2], vsum[i][3]);
       } else {
         v = *reinterpret_cast<const float4 *>(Cs + row * LDC + 4 * col4);
-        if (SPLIT) {
+        if (WSTACK) {
           const float4 lo = *reinterpret_cast<const float4 *>(Cs + row * LDC + BNO + 4 * col4);
           v.x += lo.x * kLoScale; v.y += lo.y * kLoScale; v.z += lo.z * kLoScale; v.w += lo.w * kLoScale;
         }
@@ -557,7 +598,7 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
   const int tiles = d.mtiles * d.ntiles;
   d.tile_begin = 0;
   d.tile_count = tiles;
-  if (SPLIT) {  // always 128-wide: a tile is [hi | lo] of one 64-channel group
+  if constexpr (SPLIT && sizeof(T) == 2) {  // always 128-wide: a tile is [hi | lo] of one 64-channel group
     if (d.ksplit > 1) return launch_cfg<T, 128, 2, 4, KS, 1, SPLIT>(d, tiles * d.ksplit, relu, res, s);
     if (streamk_tail > 0) {
       d.tile_begin = tiles - streamk_tail;
@@ -566,15 +607,15 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
     }
     if (tiles <= 512) return launch_cfg<T, 128, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s);
     return launch_cfg<T, 128, 2, 4, KS, 0, SPLIT>(d, tiles, relu, res, s);
-  }
+  } else {
   if (d.ksplit > 1)  // few tiles (small batch): 64-wide tiles, K split over several workgroups per tile
-    return launch_cfg<T, 64, 2, 2, KS, 1>(d, tiles * d.ksplit, relu, res, s);
+    return launch_cfg<T, 64, 2, 2, KS, 1, SPLIT>(d, tiles * d.ksplit, relu, res, s);
   if (wide && streamk_tail > 0) {
     // full rounds as plain tiles, then the rest (the partly filled last round, or a launch that is
     // less than one round) as equal shares of (tile, K-stage) units
     d.tile_begin = tiles - streamk_tail;
     d.tile_count = streamk_tail;
-    return launch_cfg<T, 128, 2, 4, KS, 2>(d, d.tile_begin + kResident, relu, res, s);
+    return launch_cfg<T, 128, 2, 4, KS, 2, SPLIT>(d, d.tile_begin + kResident, relu, res, s);
   }
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
@@ -582,10 +623,11 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
   // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.)
   const bool four = g_conv_variant == 1 || ((g_conv_variant == 0 || g_conv_variant == 6) && tiles <= 512);
   if (four)
-    return wide ? launch_cfg<T, 128, 2, 2, KS, 0>(d, tiles, relu, res, s)
-                : launch_cfg<T, 64, 2, 2, KS, 0>(d, tiles, relu, res, s);
-  if (!wide) return launch_cfg<T, 64, 4, 2, KS, 0>(d, tiles, relu, res, s);
-  return launch_cfg<T, 128, 2, 4, KS, 0>(d, tiles, relu, res, s);
+    return wide ? launch_cfg<T, 128, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s)
+                : launch_cfg<T, 64, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s);
+  if (!wide) return launch_cfg<T, 64, 4, 2, KS, 0, SPLIT>(d, tiles, relu, res, s);
+  return launch_cfg<T, 128, 2, 4, KS, 0, SPLIT>(d, tiles, relu, res, s);
+  }
 }
 
 }  // namespace
@@ -617,8 +659,8 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // 128-wide n tiles when there are enough of them to fill the chip, else 64-wide -- except that a
   // launch of 256..511 wide tiles (230 measured: no gain) with a long K loop runs wide as ONE stream-K round (block 4 at
   // batch 16, 720p: 460 wide tiles, or 920 narrow ones = 1.8 rounds, both 90 % full otherwise).
-  const bool split = p.wsplit != 0;
-  DVSG_REQUIRE(!split || p.prec == kF16, "conv_gemm: split (hi + lo) weights are a float16 layout");
+  const bool split = p.wsplit != 0 && p.prec == kF16;    // f16: hi / lo weight rows stacked along N
+  const bool psplit = p.wsplit != 0 && p.prec == kF32;   // f32s: float32 storage, products from float16 pieces
   // split weights: 128 physical weight rows per 64 output channels, always one 128-wide tile each
   const long tiles128 = split ? (long)d.mtiles * (p.Cout / 64) : p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
   const int kt_all = d.K / bke;
@@ -664,6 +706,9 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // blocks 1-3 -- as a separate split-K launch.  The hardware does not run tiles in lock-step rounds,
   // and the drain between the two launches costs more than the sliver: every such layer got 1-5 %
   // slower.)
+  if (psplit)
+    return p.ksize == 1 ? launch_ks<float, 1, true>(d, wide, streamk_tail, p.relu != 0, res, s)
+                        : launch_ks<float, 3, true>(d, wide, streamk_tail, p.relu != 0, res, s);
   if (p.prec == kF32)
     return p.ksize == 1 ? launch_ks<float, 1>(d, wide, streamk_tail, p.relu != 0, res, s)
                         : launch_ks<float, 3>(d, wide, streamk_tail, p.relu != 0, res, s);

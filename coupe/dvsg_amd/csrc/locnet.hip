@@ -33,8 +33,10 @@ struct ConvLayer {
   float *wt = nullptr;        // device, [cout][k*k*cin] float32 (conv1: [7][64][kConv1Ld])
   _Float16 *wt16 = nullptr;   // device, same layout in float16 (not for conv1)
   _Float16 *wt16s = nullptr;  // device, float16 hi / lo pairs [cout/64][128][k*k*cin] (conv_gemm.hip SPLIT; not for conv1)
+  _Float16 *wt32s = nullptr;  // device, "f32s" pieces [cout][k*k*cin/32][32 hi | 32 lo] (conv_gemm.hip SPLIT, T = float; not for conv1)
   float *bias = nullptr;      // device, [cout] float32
   const void *weights(int prec, bool split) const {
+    if (prec == kF32S) return wt32s;
     return prec == kF16 ? (split ? (const void *)wt16s : (const void *)wt16) : (const void *)wt;
   }
 };
@@ -145,9 +147,21 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
       wt16s[row * K + k] = hi;
       wt16s[(row + 64) * K + k] = lo;
     }
+  // "f32s" pieces: w ~ hi + lo, hi = f16(w), lo = f16(w - hi) (unscaled: float16 subnormals are inputs the
+  // matrix cores keep); a 32-k row stage is 128 bytes like a float32 one: 32 hi halves, then 32 lo halves
+  std::vector<_Float16> wt32s(2 * wt.size());
+  for (int n = 0; n < L->cout; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float w32 = wt[(size_t)n * K + k];
+      const _Float16 hi = (_Float16)w32;
+      const size_t base = ((size_t)n * (K / 32) + k / 32) * 64;
+      wt32s[base + k % 32] = hi;
+      wt32s[base + 32 + k % 32] = (_Float16)(w32 - (float)hi);
+    }
   if (int rc = upload(net, wt, &L->wt)) return rc;
   if (int rc = upload(net, wt16, &L->wt16)) return rc;
   if (int rc = upload(net, wt16s, &L->wt16s)) return rc;
+  if (int rc = upload(net, wt32s, &L->wt32s)) return rc;
   return upload(net, shift, &L->bias);
 }
 
@@ -263,8 +277,8 @@ int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, v
   p.splitk_scratch = ws.splitk_slabs;
   p.splitk_scratch_bytes = kSplitKSlabBytes;
   p.splitk_counters = ws.splitk_counters + (size_t)((*launch_idx)++ % kMaxConvLaunches) * kSplitKMaxTiles;
-  p.prec = prec;
-  p.wsplit = prec == kF16 && g_f16_split;
+  p.prec = prec == kF32S ? kF32 : prec;
+  p.wsplit = prec == kF32S || (prec == kF16 && g_f16_split);
   p.x = x; p.wt = L.weights(prec, p.wsplit != 0); p.bias = L.bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
@@ -549,6 +563,22 @@ int dvsg_locnet_forward_f16(const dvsg_locnet_t *net, const float *patches, int 
                  as_stream(stream));
 }
 
+int dvsg_locnet_forward_f32s(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, float *F_t,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(F_t, "dvsg_locnet_forward_f32s: NULL F_t");
+  return forward(net, kF32S, patches, B, H, W, F_t, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
+                 as_stream(stream));
+}
+
+int dvsg_locnet_forward_tap_f32s(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
+                                 float *act_out, size_t act_out_bytes, int *act_dims_host, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(act_out && act_dims_host, "dvsg_locnet_forward_tap_f32s: NULL pointer");
+  DVSG_REQUIRE(stage >= 0 && stage <= 18, "dvsg_locnet_forward_tap_f32s: stage %d outside [0,18]", stage);
+  return forward(net, kF32S, patches, B, H, W, nullptr, stage, act_out, act_out_bytes, act_dims_host, workspace,
+                 workspace_bytes, as_stream(stream));
+}
+
 int dvsg_locnet_forward_tap_f32(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
                                 float *act_out, size_t act_out_bytes, int *act_dims_host, void *workspace,
                                 size_t workspace_bytes, void *stream) {
@@ -578,6 +608,13 @@ int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const v
                        int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
                        size_t scratch_bytes, void *stream) {
   return conv_gemm_op(kF16, 0, x, wt, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+                      scratch_bytes, stream);
+}
+
+int dvsg_conv_gemm_f32s(const float *x, const void *wt_pieces, const float *bias, const float *res, float *y, int B, int H,
+                        int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+                        size_t scratch_bytes, void *stream) {
+  return conv_gemm_op(kF32, 1, x, wt_pieces, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
                       scratch_bytes, stream);
 }
 
@@ -632,6 +669,12 @@ int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const f
                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                        void *stream) {
   return stabilize(net, kF32, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+}
+
+int dvsg_stabilize_f32s(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
+                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+  return stabilize(net, kF32S, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
 }
 
 int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,

@@ -27,10 +27,11 @@ def scale_RGB(rgb):
 
 
 def _entry(base, precision):
-    """C entry point for a storage precision: "f32" (exact float32 matrix cores, the reference's
-    arithmetic) or "f16" (float16 activations / conv weights, float32 accumulation)."""
-    if precision not in ("f32", "f16"):
-        raise ValueError("precision must be 'f32' or 'f16', got %r" % (precision,))
+    """C entry point for a precision: "f32" (exact float32 matrix cores, the reference's arithmetic),
+    "f32s" (float32 storage and accumulation, products from two float16 pieces per operand: 22 significant
+    bits, float32-GEMM-level differences) or "f16" (float16 activations, hi / lo float16 weight pairs)."""
+    if precision not in ("f32", "f32s", "f16"):
+        raise ValueError("precision must be 'f32', 'f32s' or 'f16', got %r" % (precision,))
     return "%s_%s" % (base, precision)
 
 

@@ -1,0 +1,127 @@
+"""GPU: the "f32s" precision -- float32 storage and accumulation, every product of the 52 1x1 / 3x3
+convolutions formed on the float16 matrix cores from two float16 pieces per operand (22 significant
+bits; include/dvsg_amd.h, conv_gemm.hip).  It is held to the SAME bounds as the exact float32 path in
+tests/test_gpu_cnn.py / test_gpu_configs.py: stage activations <= 2e-5 relative, F_t <= 1e-5, warped
+pixels < 1e-3 at 720p outside the counted border-discontinuity pixels -- and, against the exact path
+itself, to the level at which two float32 GEMMs with different summation orders differ."""
+import numpy as np
+import pytest
+
+import inputs
+from oracle import model as omodel
+from oracle import networks as onet
+from oracle import thin_plate_spline as otps
+
+pytestmark = pytest.mark.gpu
+
+STAGES = ["conv1", "pool1"] + ["%s/unit_%d" % (b, u) for b, n in
+                                (("block1", 3), ("block2", 4), ("block3", 6), ("block4", 3))
+                                for u in range(1, n + 1)] + ["pool5"]
+
+
+@pytest.fixture(scope="module")
+def net(synthetic_weights):
+    import torch
+    assert torch.cuda.is_available()
+    from coupe.dvsg_amd.networks import LocNet
+    return LocNet(synthetic_weights)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100), (3, 33, 47), (1, 8, 8), (1, 20, 4)])
+def test_every_stage_matches_oracle(net, synthetic_weights, B, H, W):
+    x = inputs.window_frames(201, B, H, W)
+    taps = {}
+    F_ref = onet.localizationNet(x, 25, synthetic_weights, taps=taps)
+    worst = 0.0
+    for stage, name in enumerate(STAGES):
+        act = net.tap(x, stage, precision="f32s").cpu().numpy()
+        ref = taps[name]
+        if name == "pool5":
+            ref = ref.reshape(B, 1, 1, 2048)
+        assert act.shape == ref.shape, name
+        rel = np.abs(act - ref).max() / np.abs(ref).max()
+        worst = max(worst, rel)
+        assert rel <= 2e-5, "%s: relative error %.3g" % (name, rel)     # the float32 path's own bound
+    F = net.forward(x, precision="f32s").cpu().numpy()
+    assert np.abs(F - F_ref).max() <= 1e-5
+    F32 = net.forward(x, precision="f32").cpu().numpy()
+    print("f32s %dx%dx%d: worst stage %.2e, F_t vs oracle %.2e, vs the exact path %.2e"
+          % (B, H, W, worst, np.abs(F - F_ref).max(), np.abs(F - F32).max()))
+    assert np.abs(F - F32).max() <= 2e-6
+
+
+def test_layers_against_float64(net):
+    """dvsg_conv_gemm_f32s on single layers (3x3 / 1x1, stride 2, residual; small batch = split-K, large =
+    plain tiles and the stream-K tail) against float64 math on the same float32 operands: the split
+    products must be as close to it as the exact float32 kernel is, within a factor of 4."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    stream = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+    for k, stride, cin, cout, h, w, Bs in [(3, 1, 64, 64, 20, 28, 2), (3, 2, 128, 128, 21, 17, 3), (1, 1, 256, 64, 9, 13, 2),
+                                           (1, 1, 1024, 256, 23, 40, 16), (3, 1, 256, 256, 45, 80, 16), (1, 1, 128, 512, 30, 40, 16)]:
+        x = torch.rand((Bs, h, w, cin), generator=g, device=dev) * 4.0 - 1.0
+        K = k * k * cin
+        wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
+        bias = torch.rand((cout,), generator=g, device=dev) - 0.5
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        res = torch.rand((Bs, ho, wo, cout), generator=g, device=dev) - 0.5
+        hi = wt.half()
+        lo = (wt - hi.float()).half()
+        pieces = torch.cat([hi.reshape(cout, K // 32, 32), lo.reshape(cout, K // 32, 32)], 2).contiguous()
+        y32 = torch.empty((Bs, ho, wo, cout), device=dev)
+        ys = torch.empty_like(y32)
+        for fn, wts, out in (("dvsg_conv_gemm_f32", wt, y32), ("dvsg_conv_gemm_f32s", pieces, ys)):
+            _lib.call(fn, x.data_ptr(), wts.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(), Bs, h, w, cin, cout,
+                      k, stride, 1, 1, scratch.data_ptr(), scratch.numel(), stream)
+        w4 = wt.double().reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w4, bias.double(), stride=stride, padding=k // 2)
+        ref = torch.relu(ref.permute(0, 2, 3, 1) + res.double())
+        e32 = float((y32.double() - ref).abs().max())
+        es = float((ys.double() - ref).abs().max())
+        scale = float(ref.abs().max())
+        assert es <= max(4.0 * e32, 2e-6 * scale), (k, stride, cin, cout, Bs, es, e32, scale)
+
+
+def test_stabilize_720p_end_to_end(synthetic_weights):
+    """The float32 path's end-to-end bounds at 1280x720 (tests/test_gpu_configs.py::test_cfg1_*), two windows."""
+    from coupe.dvsg_amd.model import Session, StabNet
+    from oracle.cnn_torch import TorchLocNet
+    B, H, W = 2, 720, 1280
+    x = inputs.window_frames(7, B, H, W)
+    u = np.ascontiguousarray(x[..., 18:])
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    model.precision = "f32s"
+    ins, outs = model.get_evaluation_model(7)
+    pred, F, xs, ys = Session().run([outs["s_t_pred"], outs["F_t"], outs["x_offset_t"], outs["y_offset_t"]],
+                                    {ins["patches_t"]: x, ins["u_t"]: u})
+    F_ref = TorchLocNet(synthetic_weights).forward(x)
+    r_pred, r_xs, r_ys = otps.ThinPlateSpline(u, inputs.v_src(B), F_ref, (H, W))
+    border = otps.border_discontinuity_mask(r_xs, r_ys, H, W, delta=3e-2).reshape(B, H, W)
+    ferr = np.abs(F - F_ref).max()
+    gerr = max(np.abs(xs - r_xs).max() * W / 2, np.abs(ys - r_ys).max() * H / 2)
+    perr = np.abs(pred - r_pred).max(axis=3)[~border].max()
+    print("f32s at 720p: F_t %.2e, grid %.2e px, pixels %.2e" % (ferr, gerr, perr))
+    assert ferr <= 1e-5 and gerr < 2e-2 and perr < 1e-3 and border.mean() < 0.01
+
+
+def test_clip_loop_and_determinism(synthetic_weights):
+    """eval.py's 40-frame clip in this mode against the committed golden (the float32 test's bounds), twice:
+    bitwise the same both times."""
+    import os
+    from coupe.dvsg_amd.clip import stabilize_clip
+    from coupe.dvsg_amd.model import Session, StabNet
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip.npz")
+    with np.load(gold, allow_pickle=False) as z:
+        ref = z["stabilised"]
+    N, H, W = 40, 32, 48
+    frames = inputs.smooth_frames(3001, N, H, W)
+    model = StabNet(H, W).load_weights(synthetic_weights)
+    model.precision = "f32s"
+    model.get_evaluation_model(7)
+    out = stabilize_clip(model, Session(), frames)
+    err = np.abs(out - ref).reshape(N, -1)
+    assert np.median(err, axis=1).max() < 1e-5 and (err > 1e-3).mean(axis=1).max() < 0.02
+    assert np.array_equal(out, stabilize_clip(model, Session(), frames))
