@@ -78,8 +78,9 @@ constexpr int kConv1Kpad = 148;          // rounded to the 4-k MFMA step
 constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conflict-free ds_read_b64)
 // wt1h (float16 precision only): the same taps as [7][64][kConv1LdH] float16, rows zero-padded to 160.
 constexpr int kConv1LdH = 168;
-int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const float *bias, void *y,
-                 int B, int H, int W, int Ho, int Wo, hipStream_t s);
+// wt1s ("f32s" precision only): float16 pieces [7][2][64][kConv1LdH]: hi = f16(w), lo = f16((w - hi) * 2^11).
+int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const void *wt1s, const float *bias,
+                 void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
 
 // 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 8 == 0.
 int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,

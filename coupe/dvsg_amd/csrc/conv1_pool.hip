@@ -394,14 +394,161 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// conv1 for the "f32s" precision: conv1_kernel's decomposition and staging (float32 input row segment in
+// LDS, scale_RGB applied while staging, overlapping windows read in place), but the products are formed
+// on the float16 matrix cores from two float16 pieces per operand (cnn_kernels.h, conv_gemm.hip SPLIT):
+// a lane's 8 consecutive taps are read as four ds_read_b64 (42 r mod 64: conflict-free), split in
+// registers into hi = rtz_f16(x), lo = f16(x - hi), and multiplied with the weights' hi / lo pieces, which
+// sit in LDS as two [64][168]-half images per kernel row (336-byte rows: conflict-free ds_read_b128).
+// The scaled input reaches +-150, which would amplify the absolute error of an unscaled lo weight piece,
+// so here lo = f16((w - hi) x 2^11) and its products accumulate apart, folded in with 2^-11 at the end.
+// Ten 16-tap steps per kernel row (147 taps padded to 160 with zero weights): 60 MFMAs of 32 cycles per
+// wave and kernel row where the exact kernel issues 150 of 64.
+// ----------------------------------------------------------------------------------------
+constexpr int C1S_SEG_PAD = 5496;                    // floats of the staged row (reads reach tap 159 of pixel 127)
+constexpr int C1S_WHALFS = 2 * 64 * kConv1LdH;       // halves per kernel row: hi image, then lo image
+constexpr int C1S_WBYTES = C1S_WHALFS * 2;           // 43008
+
+template <typename TO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1s, const float *__restrict__ bias,
+                        TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
+  constexpr int NT = 256;
+  constexpr int INLOADS = (C1S_SEG_PAD + NT - 1) / NT;       // 22 dwords per thread per kernel row
+  constexpr int WLOADS = (C1S_WBYTES / 16 + NT - 1) / NT;    // 11 float4
+  static_assert(C1_TILE * C1_LDC * 4 <= C1S_WBYTES, "epilogue tile must fit in the weight stage");
+  __shared__ __attribute__((aligned(16))) char w_s[C1S_WBYTES];
+  __shared__ __attribute__((aligned(16))) float in_s[C1S_SEG_PAD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int blk = xcd_remap(blockIdx.x, gridDim.x);  // see conv1_kernel
+  const int wt_i = blk % wtiles;
+  blk /= wtiles;
+  const int ho = blk % Ho;
+  const int b = blk / Ho;
+  const int wo0 = wt_i * C1_TILE;
+
+  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
+  const long row_elems = (long)W * kConv1Cin;
+  float mean_i[INLOADS];
+  int idx_i[INLOADS];
+  unsigned col_ok = 0;
+#pragma unroll
+  for (int i = 0; i < INLOADS; ++i) {
+    const int e = tid + NT * i;
+    const long ge = seg0 + e;
+    const int c = e % kConv1Cin;
+    const int g = c / (kConv1Cin / 3);
+    mean_i[i] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+    const bool ok = e < C1_SEG && ge >= 0 && ge < row_elems;
+    if (ok) col_ok |= 1u << i;
+    idx_i[i] = ok ? (int)ge : 0;
+  }
+
+  float in_reg[INLOADS];
+  floatx4 w_reg[WLOADS];
+  bool row_ok = false;
+  auto load_stage = [&](int kh) __attribute__((always_inline)) {
+    const int hi = 2 * ho + kh - 3;
+    row_ok = hi >= 0 && hi < H;
+    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+    const float *xrow = x + ((long)b * H + hc) * row_elems;
+#pragma unroll
+    for (int i = 0; i < INLOADS; ++i) in_reg[i] = xrow[idx_i[i]];
+    const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1s + (size_t)kh * C1S_WHALFS);
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int q = tid + NT * i;
+      w_reg[i] = wsrc[q < C1S_WBYTES / 16 ? q : 0];
+    }
+  };
+  auto store_stage = [&]() __attribute__((always_inline)) {
+    const unsigned ok = row_ok ? col_ok : 0u;
+#pragma unroll
+    for (int i = 0; i < INLOADS; ++i) {
+      const int e = tid + NT * i;
+      const float v = in_reg[i] * 255.0f - mean_i[i];  // two roundings, like the TF ops (-ffp-contract=off)
+      if (e < C1S_SEG_PAD) in_s[e] = ((ok >> i) & 1u) ? v : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int q = tid + NT * i;
+      if (q < C1S_WBYTES / 16) reinterpret_cast<floatx4 *>(w_s)[q] = w_reg[i];
+    }
+  };
+
+  floatx16 acc[2], accl[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[mi][q] = accl[mi][q] = 0.f;
+
+  load_stage(0);
+  for (int kh = 0; kh < 7; ++kh) {
+    __syncthreads();  // everyone is done reading the previous kernel row
+    store_stage();
+    __syncthreads();
+    if (kh + 1 < 7) load_stage(kh + 1);
+    __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
+    const float *a0 = in_s + 2 * kConv1Cin * (wm * 64 + r) + 8 * h;
+    const _Float16 *bhi0 = reinterpret_cast<const _Float16 *>(w_s) + (wn * 32 + r) * kConv1LdH + 8 * h;
+    const _Float16 *blo0 = bhi0 + 64 * kConv1LdH;
+#pragma unroll 2
+    for (int t = 0; t < 10; ++t) {
+      halfx8 ahi[2], alo[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float2 *pa = reinterpret_cast<const float2 *>(a0 + mi * (2 * kConv1Cin * 32) + 16 * t);
+        const float2 q0 = pa[0], q1 = pa[1], q2 = pa[2], q3 = pa[3];
+        split_f16x2(floatx4{q0.x, q0.y, q1.x, q1.y}, floatx4{q2.x, q2.y, q3.x, q3.y}, ahi[mi], alo[mi]);
+      }
+      const halfx8 bhi = *reinterpret_cast<const halfx8 *>(bhi0 + 16 * t);
+      const halfx8 blo = *reinterpret_cast<const halfx8 *>(blo0 + 16 * t);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi, acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi, acc[mi], 0, 0, 0);
+        accl[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo, accl[mi], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: fold the scaled lo products in, transpose through the (idle) weight stage
+  float *Cs = reinterpret_cast<float *>(w_s);
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      Cs[(wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + wn * 32 + r] = acc[mi][q] + accl[mi][q] * (1.0f / 2048.0f);
+  __syncthreads();
+  const int col4 = tid & 15, row0 = tid >> 4;
+  const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
+  TO *yrow = y + (((size_t)b * Ho + ho) * Wo + wo0) * 64 + 4 * col4;
+#pragma unroll 4
+  for (int row = row0; row < C1_TILE; row += 16) {
+    if (wo0 + row >= Wo) break;
+    float4 v = *reinterpret_cast<const float4 *>(Cs + row * C1_LDC + 4 * col4);
+    v.x = fmaxf(v.x + b4.x, 0.f);
+    v.y = fmaxf(v.y + b4.y, 0.f);
+    v.z = fmaxf(v.z + b4.z, 0.f);
+    v.w = fmaxf(v.w + b4.w, 0.f);
+    store4(yrow + (size_t)row * 64, v);
+  }
+}
+
 int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 waves (measured equal or better), 1 = 8
 
 }  // namespace
 
 void set_conv1_variant(int v) { g_conv1_variant = v; }
 
-int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const float *bias, void *y,
-                 int B, int H, int W, int Ho, int Wo, hipStream_t s) {
+int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const void *wt1s, const float *bias,
+                 void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s) {
   const int wtiles = ceil_div(Wo, C1_TILE);
   const long blocks = (long)wtiles * Ho * B;
   DVSG_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv1: grid of %ld workgroups out of range", blocks);
@@ -409,7 +556,10 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1
   ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
                  4.0 * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
   const dim3 grid((unsigned)blocks);
-  if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
+  if (out_prec == kF32S && wt1s && g_conv1_variant != 2) {
+    hipLaunchKernelGGL((conv1_split_kernel<float>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s), bias,
+                       static_cast<float *>(y), H, W, Ho, Wo, wtiles);
+  } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
     hipLaunchKernelGGL((conv1_f16_kernel<_Float16>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
                        bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
   } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output

@@ -188,8 +188,19 @@ int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Co
     for (int n = 0; n < 64; ++n)
       for (int k = 0; k < kConv1K; ++k)
         wth[((size_t)kh * 64 + n) * kConv1LdH + k] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k];
+  // "f32s" pieces, [7][2][64][kConv1LdH]: hi image then lo image per kernel row, lo scaled by 2^11 (conv1_split_kernel)
+  std::vector<_Float16> wts((size_t)7 * 2 * 64 * kConv1LdH, (_Float16)0.f);
+  for (int kh = 0; kh < 7; ++kh)
+    for (int n = 0; n < 64; ++n)
+      for (int k = 0; k < kConv1K; ++k) {
+        const float w32 = wt[((size_t)kh * 64 + n) * kConv1Ld + k];
+        const _Float16 hi = (_Float16)w32;
+        wts[(((size_t)kh * 2 + 0) * 64 + n) * kConv1LdH + k] = hi;
+        wts[(((size_t)kh * 2 + 1) * 64 + n) * kConv1LdH + k] = (_Float16)((w32 - (float)hi) * 2048.0f);
+      }
   if (int rc = upload(net, wt, &L->wt)) return rc;
   if (int rc = upload(net, wth, &L->wt16)) return rc;
+  if (int rc = upload(net, wts, &L->wt32s)) return rc;
   return upload(net, shift, &L->bias);
 }
 
@@ -328,8 +339,8 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
   DVSG_HIP(hipMemsetAsync(ws.splitk_counters, 0, (size_t)kMaxConvLaunches * kSplitKMaxTiles * sizeof(int), s));
   int launch_idx = 0;
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
-  DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.wt16, net->conv1.bias, ws.bufA, B, H, W, d.H1,
-                        d.W1, s));
+  DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s, net->conv1.bias, ws.bufA, B, H,
+                        W, d.H1, d.W1, s));
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
   DVSG_RUN(launch_maxpool(prec, ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
   DVSG_TAP(1, ws.bufB, d.Hp, d.Wp, 64);
