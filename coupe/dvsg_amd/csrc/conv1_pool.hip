@@ -395,18 +395,23 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------
-// conv1 for the "f32s" precision: conv1_kernel's decomposition and staging (float32 input row segment in
-// LDS, scale_RGB applied while staging, overlapping windows read in place), but the products are formed
-// on the float16 matrix cores from two float16 pieces per operand (cnn_kernels.h, conv_gemm.hip SPLIT):
-// a lane's 8 consecutive taps are read as four ds_read_b64 (42 r mod 64: conflict-free), split in
-// registers into hi = rtz_f16(x), lo = f16(x - hi), and multiplied with the weights' hi / lo pieces, which
-// sit in LDS as two [64][168]-half images per kernel row (336-byte rows: conflict-free ds_read_b128).
-// The scaled input reaches +-150, which would amplify the absolute error of an unscaled lo weight piece,
-// so here lo = f16((w - hi) x 2^11) and its products accumulate apart, folded in with 2^-11 at the end.
+// conv1 for the "f32s" precision: conv1_kernel's decomposition and staging (one output row x 128 pixels x
+// 64 channels per workgroup, the input row segment prefetched into registers under the previous kernel
+// row's MFMAs, scale_RGB applied while staging, overlapping windows read in place), with the products
+// formed on the float16 matrix cores from two float16 pieces per operand (cnn_kernels.h, conv_gemm.hip).
+// The scaled input is split ONCE, when it is staged -- hi = f16(v), lo = f16(v - hi), two float16 images
+// of the row in LDS, together as large as the float32 row was -- so the 7 overlapping windows and the two
+// channel halves that read an element do not split it again: a lane's operand is 8 consecutive taps =
+// 16 bytes at byte offset 84 pixel + 32 step + 16 h of either image, four ds_read_b32 (21 r mod 32 is a
+// bijection: conflict-free).  The weights' pieces sit in LDS as two [64][168]-half images per kernel row
+// (336-byte rows: conflict-free ds_read_b128), prefetched through registers like the input.  The scaled
+// input reaches +-150, which would amplify the absolute error of an unscaled lo weight piece, so here
+// lo_w = f16((w - hi_w) x 2^11) and its products accumulate apart, folded in with 2^-11 at the end.
 // Ten 16-tap steps per kernel row (147 taps padded to 160 with zero weights): 60 MFMAs of 32 cycles per
 // wave and kernel row where the exact kernel issues 150 of 64.
 // ----------------------------------------------------------------------------------------
-constexpr int C1S_SEG_PAD = 5496;                    // floats of the staged row (reads reach tap 159 of pixel 127)
+constexpr int C1S_SEG = 5504;                        // halves per staged image of the row (5481 + zero tail; reads reach 5494)
+constexpr int C1S_INPAIRS = (C1S_SEG / 2 + 255) / 256;  // 11 pairs per thread
 constexpr int C1S_WHALFS = 2 * 64 * kConv1LdH;       // halves per kernel row: hi image, then lo image
 constexpr int C1S_WBYTES = C1S_WHALFS * 2;           // 43008
 
@@ -415,11 +420,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1s, const float *__restrict__ bias,
                         TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
   constexpr int NT = 256;
-  constexpr int INLOADS = (C1S_SEG_PAD + NT - 1) / NT;       // 22 dwords per thread per kernel row
   constexpr int WLOADS = (C1S_WBYTES / 16 + NT - 1) / NT;    // 11 float4
   static_assert(C1_TILE * C1_LDC * 4 <= C1S_WBYTES, "epilogue tile must fit in the weight stage");
   __shared__ __attribute__((aligned(16))) char w_s[C1S_WBYTES];
-  __shared__ __attribute__((aligned(16))) float in_s[C1S_SEG_PAD];
+  __shared__ __attribute__((aligned(16))) unsigned in_hi[C1S_SEG / 2], in_lo[C1S_SEG / 2];  // half2 per word
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -434,12 +438,12 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
 
   const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[INLOADS];
-  int idx_i[INLOADS];
+  float mean_i[2 * C1S_INPAIRS];
+  int idx_i[2 * C1S_INPAIRS];
   unsigned col_ok = 0;
 #pragma unroll
-  for (int i = 0; i < INLOADS; ++i) {
-    const int e = tid + NT * i;
+  for (int i = 0; i < 2 * C1S_INPAIRS; ++i) {
+    const int e = 2 * (tid + NT * (i >> 1)) + (i & 1);
     const long ge = seg0 + e;
     const int c = e % kConv1Cin;
     const int g = c / (kConv1Cin / 3);
@@ -449,7 +453,7 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     idx_i[i] = ok ? (int)ge : 0;
   }
 
-  float in_reg[INLOADS];
+  float in_reg[2 * C1S_INPAIRS];
   floatx4 w_reg[WLOADS];
   bool row_ok = false;
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
@@ -458,7 +462,7 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = x + ((long)b * H + hc) * row_elems;
 #pragma unroll
-    for (int i = 0; i < INLOADS; ++i) in_reg[i] = xrow[idx_i[i]];
+    for (int i = 0; i < 2 * C1S_INPAIRS; ++i) in_reg[i] = xrow[idx_i[i]];
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1s + (size_t)kh * C1S_WHALFS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -467,12 +471,23 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     }
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const unsigned ok = row_ok ? col_ok : 0u;
 #pragma unroll
-    for (int i = 0; i < INLOADS; ++i) {
-      const int e = tid + NT * i;
-      const float v = in_reg[i] * 255.0f - mean_i[i];  // two roundings, like the TF ops (-ffp-contract=off)
-      if (e < C1S_SEG_PAD) in_s[e] = ((ok >> i) & 1u) ? v : 0.f;
+    for (int i = 0; i < C1S_INPAIRS; ++i) {
+      const int q = tid + NT * i;
+      // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops: -ffp-contract=off), then the two pieces
+      const float v0 = ((ok >> (2 * i)) & 1u) ? in_reg[2 * i] * 255.0f - mean_i[2 * i] : 0.f;
+      const float v1 = ((ok >> (2 * i + 1)) & 1u) ? in_reg[2 * i + 1] * 255.0f - mean_i[2 * i + 1] : 0.f;
+      half2_t hv, lv;
+      hv[0] = (_Float16)v0;
+      hv[1] = (_Float16)v1;
+      lv[0] = (_Float16)(v0 - (float)hv[0]);
+      lv[1] = (_Float16)(v1 - (float)hv[1]);
+      if (q < C1S_SEG / 2) {
+        in_hi[q] = __builtin_bit_cast(unsigned, hv);
+        in_lo[q] = __builtin_bit_cast(unsigned, lv);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -494,25 +509,32 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     __syncthreads();
     if (kh + 1 < 7) load_stage(kh + 1);
     __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
-    const float *a0 = in_s + 2 * kConv1Cin * (wm * 64 + r) + 8 * h;
+    // word index of the lane's first tap pair: (42 pixel + 8 h) / 2
+    const int a0 = kConv1Cin * (wm * 64 + r) + 4 * h;
     const _Float16 *bhi0 = reinterpret_cast<const _Float16 *>(w_s) + (wn * 32 + r) * kConv1LdH + 8 * h;
     const _Float16 *blo0 = bhi0 + 64 * kConv1LdH;
 #pragma unroll 2
     for (int t = 0; t < 10; ++t) {
-      halfx8 ahi[2], alo[2];
+      union {
+        unsigned u[4];
+        halfx8 v;
+      } ahi[2], alo[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        const float2 *pa = reinterpret_cast<const float2 *>(a0 + mi * (2 * kConv1Cin * 32) + 16 * t);
-        const float2 q0 = pa[0], q1 = pa[1], q2 = pa[2], q3 = pa[3];
-        split_f16x2(floatx4{q0.x, q0.y, q1.x, q1.y}, floatx4{q2.x, q2.y, q3.x, q3.y}, ahi[mi], alo[mi]);
+        const int w0 = a0 + mi * (kConv1Cin * 32) + 8 * t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ahi[mi].u[j] = in_hi[w0 + j];
+          alo[mi].u[j] = in_lo[w0 + j];
+        }
       }
       const halfx8 bhi = *reinterpret_cast<const halfx8 *>(bhi0 + 16 * t);
       const halfx8 blo = *reinterpret_cast<const halfx8 *>(blo0 + 16 * t);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi, acc[mi], 0, 0, 0);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi, acc[mi], 0, 0, 0);
-        accl[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo, accl[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi].v, bhi, acc[mi], 0, 0, 0);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi].v, bhi, acc[mi], 0, 0, 0);
+        accl[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi].v, blo, accl[mi], 0, 0, 0);
       }
     }
   }
