@@ -48,25 +48,25 @@ struct Frag<_Float16> {
   }
 };
 
-// "f32s" products: eight float32 values (two 16-byte chunks, consecutive k) -> their float16 pieces
-// hi = rtz_f16(x) and lo = f16(x - hi).  x - hi is exact in float32 (hi is x truncated to 11 significant
-// bits), so hi + lo carries 22 significant bits of x; lo may be a float16 subnormal, which the matrix
-// cores keep.  4 v_cvt_pkrtz + 8 v_cvt_f32_f16 + 8 subtractions + 4 v_cvt_pkrtz per 8 values.
-__device__ __forceinline__ void split_f16x2(floatx4 f0, floatx4 f1, halfx8 &hi, halfx8 &lo) {
-  typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-  typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
-  const float f[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(f[2 * i], f[2 * i + 1]);
-    const halfx2 h2 = __builtin_bit_cast(halfx2, hp);
-    hi[2 * i] = h2[0];
-    hi[2 * i + 1] = h2[1];
-    const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(f[2 * i] - (float)h2[0], f[2 * i + 1] - (float)h2[1]);
-    const halfx2 l2 = __builtin_bit_cast(halfx2, lp);
-    lo[2 * i] = l2[0];
-    lo[2 * i + 1] = l2[1];
-  }
+// "f32s" activation tensors are stored as their two float16 pieces (P format): flat element e of a dense
+// NHWC tensor whose channel count is a multiple of 32 lives in 128-byte group e / 32 -- 32 hi halves, then 32
+// lo halves -- exactly the layout of a weight row stage, so a conv GEMM's LDS-DMA moves such rows as it moves
+// float32 ones and a fragment is two ds_read_b128 with no arithmetic.  hi = f16(v), lo = f16(v - hi): hi + lo
+// is exact in float32 and carries 22 significant bits of v.
+__device__ __forceinline__ float4 load4_p(const void *base, size_t e) {
+  const char *q = static_cast<const char *>(base) + (e >> 5) * 128 + (e & 31) * 2;
+  const halfx4 hi = *reinterpret_cast<const halfx4 *>(q), lo = *reinterpret_cast<const halfx4 *>(q + 64);
+  return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2],
+                     (float)hi[3] + (float)lo[3]);
+}
+__device__ __forceinline__ void store4_p(void *base, size_t e, float4 v) {
+  char *q = static_cast<char *>(base) + (e >> 5) * 128 + (e & 31) * 2;
+  halfx4 hi, lo;
+  hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+  lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+  lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+  *reinterpret_cast<halfx4 *>(q) = hi;
+  *reinterpret_cast<halfx4 *>(q + 64) = lo;
 }
 
 // Four consecutive channels of an activation tensor <-> float4.

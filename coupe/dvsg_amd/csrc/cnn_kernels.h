@@ -11,9 +11,9 @@
 
 namespace dvsg {
 
-// kF32S: float32 storage and accumulation like kF32, but the 1x1 / 3x3 convolutions form their products
-// on the float16 matrix cores from two float16 pieces per operand (22 significant bits; conv_gemm.hip).
-// Everything that is not a conv_gemm launch treats it as kF32.
+// kF32S: 4 bytes per value and float32 accumulation like kF32, but every product is formed on the float16
+// matrix cores from two float16 pieces per operand (22 significant bits; conv_gemm.hip), and the activation
+// tensors between the layers hold those two pieces (P format, cnn_device.h) instead of one float32.
 enum Precision { kF32 = 0, kF16 = 1, kF32S = 2 };
 inline size_t elem_size(int prec) { return prec == kF16 ? 2 : 4; }
 
@@ -92,6 +92,9 @@ int launch_avgpool_partial(int prec, const void *x, float *part, int B, int HW, 
 
 // Element-wise float16 -> float32 (parity taps of a float16 run).
 int launch_f16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
+// P format ("f32s" activations: float16 pieces, cnn_device.h) <-> float32; n % 32 == 0.
+int launch_p_to_f32(const void *x, float *y, size_t n, hipStream_t s);
+int launch_f32_to_p(const float *x, void *y, size_t n, hipStream_t s);
 
 // Dense layer on split partial sums (see head.hip); float32 throughout.
 constexpr int kDenseSplits = 8;

@@ -550,7 +550,6 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   __syncthreads();
   const int col4 = tid & 15, row0 = tid >> 4;
   const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
-  TO *yrow = y + (((size_t)b * Ho + ho) * Wo + wo0) * 64 + 4 * col4;
 #pragma unroll 4
   for (int row = row0; row < C1_TILE; row += 16) {
     if (wo0 + row >= Wo) break;
@@ -559,8 +558,38 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     v.y = fmaxf(v.y + b4.y, 0.f);
     v.z = fmaxf(v.z + b4.z, 0.f);
     v.w = fmaxf(v.w + b4.w, 0.f);
-    store4(yrow + (size_t)row * 64, v);
+    store4_p(y, (((size_t)b * Ho + ho) * Wo + wo0 + row) * 64 + 4 * col4, v);   // float16 pieces (cnn_device.h)
   }
+}
+
+// max pool on a P-format tensor ("f32s"): the pieces are joined (exact), compared, and the maximum's pieces stored
+__global__ __launch_bounds__(256) void maxpool_p_kernel(const void *__restrict__ x, void *__restrict__ y, int H, int W,
+                                                       int C4, int Ho, int Wo, int pad_top, int pad_left, size_t total) {
+  const size_t e = (size_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c4 = (int)(e % C4);
+  size_t t = e / C4;
+  const int wo = (int)(t % Wo);
+  t /= Wo;
+  const int ho = (int)(t % Ho);
+  const size_t b = t / Ho;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int hi = 2 * ho - pad_top + i;
+    if (hi < 0 || hi >= H) continue;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int wi = 2 * wo - pad_left + j;
+      if (wi < 0 || wi >= W) continue;
+      const float4 v = load4_p(x, (((b * H + hi) * W + wi) * C4 + c4) * 4);
+      m.x = fmaxf(m.x, v.x);
+      m.y = fmaxf(m.y, v.y);
+      m.z = fmaxf(m.z, v.z);
+      m.w = fmaxf(m.w, v.w);
+    }
+  }
+  store4_p(y, e * 4, m);
 }
 
 int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 waves (measured equal or better), 1 = 8
@@ -605,13 +634,15 @@ extern "C" int dvsg_debug_read_conv1_stamps(void *host, size_t bytes) {
 
 int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
                    int pad_left, hipStream_t s) {
-  DVSG_REQUIRE(C % 4 == 0, "maxpool: C=%d must be a multiple of 4", C);
+  DVSG_REQUIRE(C % 4 == 0 && (prec != kF32S || C % 32 == 0), "maxpool: C=%d must be a multiple of 4 (32 in the f32s format)", C);
   const size_t total = (size_t)B * Ho * Wo * (C / 4);
   const size_t want = (total + 255) / 256;
   DVSG_REQUIRE(want < (1u << 31), "maxpool: %zu blocks do not fit a grid", want);
   const int blocks = (int)want;
   ProfScope prof(kClsMaxpool, s, 0.0, (double)elem_size(prec) * C * ((double)B * H * W + (double)B * Ho * Wo));
-  if (prec == kF16)
+  if (prec == kF32S)
+    hipLaunchKernelGGL(maxpool_p_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, C / 4, Ho, Wo, pad_top, pad_left, total);
+  else if (prec == kF16)
     hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16 *>(x),
                        static_cast<_Float16 *>(y), H, W, C / 4, Ho, Wo, pad_top, pad_left, total);
   else

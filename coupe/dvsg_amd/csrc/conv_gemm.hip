@@ -105,9 +105,12 @@ struct ConvGemmDev {
 // x1 = rtz_f16(x), x2 = f16(x - x1): 22 significant bits.  a w ~ a1 w1 + a2 w1 + a1 w2 (the dropped a2 w2
 // is 2^-22 relative), each float16 product exact in float32 -- three v_mfma_f32_32x32x16_f16 (96 cycles)
 // where the exact path issues eight v_mfma_f32_32x32x2_f32 (512 cycles).  Activations are split in
-// registers right after the fragment read (~24 VALU per 8 values, under the other waves' MFMAs), weights
-// once at load: a weight row stage is 128 bytes like a float32 one -- 32 hi halves, then 32 lo halves --
-// so tiles, LDS-DMA and swizzle are the float32 kernel's, byte for byte.  float16 subnormals are inputs
+// once by their producer (an epilogue stores the two pieces of each value: cnn_device.h, P format), weights
+// once at load: an activation or weight row stage is 128 bytes like a float32 one -- 32 hi halves, then 32
+// lo halves -- so tiles, LDS-DMA and swizzle are the float32 kernel's, byte for byte, and the main loop
+// has no arithmetic but the MFMAs.  (Splitting the float32 activations in registers after the fragment
+// read instead -- ~24 VALU per 8 values and wave -- ran the same layers at 270 instead of ... TFLOP/s and
+// held the shader clock at 1.79 GHz.)  float16 subnormals are inputs
 // the matrix cores keep (tools/f16_subnormal_probe.hip), so nothing is scaled.  Against the exact path:
 // stage activations within 2e-6 relative, F_t within 1e-7 (a CPU emulation of the arithmetic and the GPU
 // tests agree), i.e. at the level at which two float32 GEMMs with different summation orders differ.
@@ -268,17 +271,16 @@ void conv_gemm_kernel(ConvGemmDev p) {
       const char *a_base = As + (buf * BM + wm * (BM / WM) + r) * ROWB;
       const char *b_base = Bs + (buf * BN + wn * (BN / WN) + r) * ROWB;
       if constexpr (PSPLIT) {
-        // two 16-k MFMA steps per 32-k stage; lane half h owns the k-run of 8 number g = 2 t + h:
-        // activations = float32 chunks 2g, 2g+1 of the row, weights = half chunk g (hi) and 4 + g (lo)
+        // two 16-k MFMA steps per 32-k stage; lane half h owns the k-run of 8 number g = 2 t + h: its hi
+        // pieces are 16-byte chunk g of the row, its lo pieces chunk 4 + g -- activations and weights alike
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int g = 2 * t + h;
           halfx8 ahi[MI], alo[MI];
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
-            const floatx4 f0 = *reinterpret_cast<const floatx4 *>(a_base + mi * 32 * ROWB + 16 * ((2 * g) ^ sw));
-            const floatx4 f1 = *reinterpret_cast<const floatx4 *>(a_base + mi * 32 * ROWB + 16 * ((2 * g + 1) ^ sw));
-            split_f16x2(f0, f1, ahi[mi], alo[mi]);
+            ahi[mi] = *reinterpret_cast<const halfx8 *>(a_base + mi * 32 * ROWB + 16 * (g ^ sw));
+            alo[mi] = *reinterpret_cast<const halfx8 *>(a_base + mi * 32 * ROWB + 16 * ((4 + g) ^ sw));
           }
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
@@ -351,7 +353,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
           const int b = t / p.Ho;
           roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
         }
-        rv[i] = load4(pres + roff);
+        rv[i] = PSPLIT ? load4_p(p.res, roff) : load4(pres + roff);
       }
     };
     DVSG_STAMP(1);
@@ -494,7 +496,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
             const int b = t / p.Ho;
             roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
           }
-          r4 = load4(pres + roff);
+          r4 = PSPLIT ? load4_p(p.res, roff) : load4(pres + roff);
         } else {
           r4 = rv[i];
         }
@@ -503,7 +505,8 @@ void conv_gemm_kernel(ConvGemmDev p) {
       if (RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      store4(py + (size_t)m * p.Cout + n, v);
+      if (PSPLIT) store4_p(p.y, (size_t)m * p.Cout + n, v);
+      else store4(py + (size_t)m * p.Cout + n, v);
     }
   };
 
@@ -615,13 +618,14 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
     // less than one round) as equal shares of (tile, K-stage) units
     d.tile_begin = tiles - streamk_tail;
     d.tile_count = streamk_tail;
+    if (SPLIT && g_conv_variant == 8) return launch_cfg<T, 128, 2, 2, KS, 2, SPLIT>(d, d.tile_begin + kResident, relu, res, s);
     return launch_cfg<T, 128, 2, 4, KS, 2, SPLIT>(d, d.tile_begin + kResident, relu, res, s);
   }
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
   // waves in flight.  (A 4-stage LDS-DMA ring, 96 KB of LDS and one workgroup per CU, was measured
   // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.)
-  const bool four = g_conv_variant == 1 || ((g_conv_variant == 0 || g_conv_variant == 6) && tiles <= 512);
+  const bool four = g_conv_variant == 1 || g_conv_variant == 8 || ((g_conv_variant == 0 || g_conv_variant == 6) && tiles <= 512);
   if (four)
     return wide ? launch_cfg<T, 128, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s)
                 : launch_cfg<T, 64, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s);
@@ -665,7 +669,7 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   const long tiles128 = split ? (long)d.mtiles * (p.Cout / 64) : p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
   const int kt_all = d.K / bke;
   const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
-  const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes && res == 0;
+  const bool streamk_ok = (g_conv_variant == 0 || g_conv_variant == 8) && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes && res == 0;
   const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
   const bool wide = split || (g_conv_variant != 4 && (tiles128 >= kResident || streamk_all));
   d.ntiles = split ? p.Cout / 64 : p.Cout / (wide ? 128 : 64);

@@ -33,6 +33,34 @@ __global__ __launch_bounds__(256) void avgpool_partial_kernel(const T *__restric
   part[((size_t)b * kPoolSplits + s) * C + c] = acc;
 }
 
+// the same sums over a P-format tensor ("f32s": float16 pieces, cnn_device.h); channel c of pixel i is flat element i C + c
+__global__ __launch_bounds__(256) void avgpool_partial_p_kernel(const void *__restrict__ x, float *__restrict__ part, int B,
+                                                               int HW, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, s = blockIdx.z;
+  if (c >= C) return;
+  const int per = (HW + kPoolSplits - 1) / kPoolSplits;
+  const int i0 = s * per, i1 = min(HW, i0 + per);
+  const char *base = static_cast<const char *>(x);
+  float acc = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const size_t e = ((size_t)b * HW + i) * C + c;
+    const char *q = base + (e >> 5) * 128 + (e & 31) * 2;
+    acc += (float)*reinterpret_cast<const _Float16 *>(q) + (float)*reinterpret_cast<const _Float16 *>(q + 64);
+  }
+  part[((size_t)b * kPoolSplits + s) * C + c] = acc;
+}
+
+// P format <-> float32 (parity taps, layer-level tests); n elements, n % 4 == 0
+__global__ __launch_bounds__(256) void p_to_f32_kernel(const void *__restrict__ x, float *__restrict__ y, size_t n4) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256)
+    *reinterpret_cast<float4 *>(y + 4 * e) = load4_p(x, 4 * e);
+}
+__global__ __launch_bounds__(256) void f32_to_p_kernel(const float *__restrict__ x, void *__restrict__ y, size_t n4) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256)
+    store4_p(y, 4 * e, *reinterpret_cast<const float4 *>(x + 4 * e));
+}
+
 constexpr int kDenseMaxB = 16;
 constexpr int kDenseKC = 256;
 
@@ -135,9 +163,27 @@ int launch_f16_to_f32(const void *x, float *y, size_t n, hipStream_t s) {
   return check_launch("f16_to_f32_kernel");
 }
 
+int launch_p_to_f32(const void *x, float *y, size_t n, hipStream_t s) {
+  DVSG_REQUIRE(n % 32 == 0, "p_to_f32: %zu elements are not whole 32-element groups", n);
+  const size_t want = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(p_to_f32_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, x, y, n / 4);
+  return check_launch("p_to_f32_kernel");
+}
+
+int launch_f32_to_p(const float *x, void *y, size_t n, hipStream_t s) {
+  DVSG_REQUIRE(n % 32 == 0, "f32_to_p: %zu elements are not whole 32-element groups", n);
+  const size_t want = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(f32_to_p_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, x, y, n / 4);
+  return check_launch("f32_to_p_kernel");
+}
+
 int launch_avgpool_partial(int prec, const void *x, float *part, int B, int HW, int C, hipStream_t s) {
   ProfScope prof(kClsHead, s, 0.0, (double)elem_size(prec) * B * HW * C);
   const dim3 grid(ceil_div(C, 256), B, kPoolSplits);
+  if (prec == kF32S) {
+    hipLaunchKernelGGL(avgpool_partial_p_kernel, grid, dim3(256), 0, s, x, part, B, HW, C);
+    return check_launch("avgpool_partial_p_kernel");
+  }
   if (prec == kF16)
     hipLaunchKernelGGL(avgpool_partial_kernel<_Float16>, grid, dim3(256), 0, s, static_cast<const _Float16 *>(x),
                        part, B, HW, C);

@@ -318,6 +318,8 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
       return fail(DVSG_ERR_INVALID_ARG, "tap buffer %zu bytes < %zu", act_out_bytes, n * sizeof(float));
     if (prec == kF16) {
       if (int rc = launch_f16_to_f32(act, act_out, n, s)) return rc;
+    } else if (prec == kF32S) {
+      if (int rc = launch_p_to_f32(act, act_out, n, s)) return rc;
     } else {
       DVSG_HIP(hipMemcpyAsync(act_out, act, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
@@ -622,11 +624,21 @@ int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const v
                       scratch_bytes, stream);
 }
 
-int dvsg_conv_gemm_f32s(const float *x, const void *wt_pieces, const float *bias, const float *res, float *y, int B, int H,
+int dvsg_conv_gemm_f32s(const void *x, const void *wt_pieces, const float *bias, const void *res, void *y, int B, int H,
                         int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
                         size_t scratch_bytes, void *stream) {
   return conv_gemm_op(kF32, 1, x, wt_pieces, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
                       scratch_bytes, stream);
+}
+
+int dvsg_f32_to_pieces(const float *x, void *y, size_t n, void *stream) {
+  DVSG_REQUIRE(x && y, "dvsg_f32_to_pieces: NULL pointer");
+  return launch_f32_to_p(x, y, n, as_stream(stream));
+}
+
+int dvsg_pieces_to_f32(const void *x, float *y, size_t n, void *stream) {
+  DVSG_REQUIRE(x && y, "dvsg_pieces_to_f32: NULL pointer");
+  return launch_p_to_f32(x, y, n, as_stream(stream));
 }
 
 int dvsg_conv_gemm_f16s(const void *x, const void *wt_split, const float *bias, const void *res, void *y, int B, int H,

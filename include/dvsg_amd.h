@@ -197,10 +197,12 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
 /* ---------------------------------------------------------------------------------------
  * "f32s": float32 storage, float32 accumulation, float32-equivalent PRODUCTS from the float16 matrix
  * cores.  Same tensors, same workspace, same launch sequence as the *_f32 entry points (conv1, the max
- * pool, the dense head, the TPS solve and the warp are the float32 kernels themselves); in the 52
- * 1x1 / 3x3 convolutions every operand enters the matrix cores as two float16 pieces, x ~ rtz_f16(x) +
- * f16(x - rtz_f16(x)) (22 significant bits), and a product is three v_mfma_f32_32x32x16_f16 -- a1 w1 +
- * a2 w1 + a1 w2, each exact in float32 -- instead of eight v_mfma_f32_32x32x2_f32.  Measured against the
+ * dense head, the TPS solve and the warp are the float32 kernels themselves); in conv1 and the 52 1x1 / 3x3
+ * convolutions every operand enters the matrix cores as two float16 pieces, x ~ f16(x) + f16(x - f16(x))
+ * (22 significant bits), and a product is three v_mfma_f32_32x32x16_f16 -- a1 w1 + a2 w1 + a1 w2, each
+ * exact in float32 -- instead of eight v_mfma_f32_32x32x2_f32.  The activation tensors between the layers
+ * (library workspace) hold the two pieces of each value instead of one float32, so they are split once,
+ * by the layer that produces them.  Measured against the
  * exact path: stage activations within 2e-6 relative, F_t within 1e-7, i.e. what two float32 GEMMs with
  * different summation orders differ by; every float32 parity test of tests/ also passes in this mode
  * (tests/test_gpu_f32s.py).  It is NOT the exact float32 arithmetic of the reference and is therefore a
@@ -215,11 +217,16 @@ int dvsg_locnet_forward_tap_f32s(const dvsg_locnet_t *net, const float *patches,
 int dvsg_stabilize_f32s(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B,
                         int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
                         void *workspace, size_t workspace_bytes, void *stream);
-/* One layer in that mode: x, res, y float32; wt_pieces is [Cout][K/32][32 hi halves | 32 lo halves]
- * float16 (hi = f16(w), lo = f16(w - hi)): a 32-k row stage is 128 bytes, like a float32 one. */
-int dvsg_conv_gemm_f32s(const float *x, const void *wt_pieces, const float *bias, const float *res,
-                        float *y, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+/* One layer in that mode.  x, res, y are activation tensors in the mode's INTERNAL format: 4 bytes per
+ * value, but as the value's two float16 pieces -- flat element e of the dense NHWC tensor (channels % 32
+ * == 0) lives in 128-byte group e / 32: 32 hi halves, then 32 lo halves (dvsg_f32_to_pieces /
+ * dvsg_pieces_to_f32 convert).  wt_pieces is [Cout][K/32][32 hi halves | 32 lo halves] float16 (hi = f16(w),
+ * lo = f16(w - hi)).  A 32-k row stage of either operand is 128 bytes, like a float32 one. */
+int dvsg_conv_gemm_f32s(const void *x, const void *wt_pieces, const float *bias, const void *res,
+                        void *y, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                         int relu, int res_stride, void *scratch, size_t scratch_bytes, void *stream);
+int dvsg_f32_to_pieces(const float *x, void *y, size_t n, void *stream);   /* n % 32 == 0 */
+int dvsg_pieces_to_f32(const void *x, float *y, size_t n, void *stream);
 
 /* x, wt, res, y are float16 (Cin % 64 == 0); bias float32. */
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y,

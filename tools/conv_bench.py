@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--variants", default="1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", default="uniq")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f16"])
     ap.add_argument("--rep", type=int, default=20,
                     help="back-to-back launches per timing (1 = isolated launches: the clock governor has not ramped "
                          "and short kernels read 10-15 %% low, DESIGN.md 5.0)")
@@ -69,6 +69,10 @@ def main():
         x = (torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3).to(dt)
         K = k * k * cin
         wt = ((torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)).to(dt)
+        if args.precision == "f32s":   # float16 pieces [Cout][K/32][32 hi | 32 lo]; activations: any 4-byte buffers time alike
+            hi = wt.half()
+            lo = (wt - hi.float()).half()
+            wt = torch.cat([hi.reshape(cout, K // 32, 32), lo.reshape(cout, K // 32, 32)], 2).contiguous()
         bias = torch.rand((cout,), generator=g, device=dev) - 0.5
         res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5).to(dt) if has_res else None
         y = torch.empty((B, ho, wo, cout), device=dev, dtype=dt)

@@ -18,16 +18,22 @@ for arg in sys.argv[1:]:
     wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
     bias = torch.rand((cout,), generator=g, device=dev) - 0.5
     y = torch.empty((B, H, W, cout), device=dev)
+    FN = "dvsg_conv_gemm_f32"
+    if os.environ.get("PROBE_PREC") == "f32s":   # float16 pieces [Cout][K/32][32 hi | 32 lo]
+        FN = "dvsg_conv_gemm_f32s"
+        hi = wt.half()
+        lo = (wt - hi.float()).half()
+        wt = torch.cat([hi.reshape(cout, K // 32, 32), lo.reshape(cout, K // 32, 32)], 2).contiguous()
     scratch = torch.zeros(66 << 20, dtype=torch.uint8, device=dev)
     _lib.call("dvsg_debug_set_option", b"conv_variant", 6)   # no stream-K: every tile is a mode-0 workgroup
     REP = int(os.environ.get("PROBE_REP", "1"))     # back-to-back launches before the measured one (clock governor settles)
     for rnd in range(3):
         for _ in range(REP - 1):
-            _lib.call("dvsg_conv_gemm_f32", x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y.data_ptr(), B, H, W, cin, cout, k,
+            _lib.call(FN, x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y.data_ptr(), B, H, W, cin, cout, k,
                       1, 1, 1, scratch.data_ptr(), scratch.numel(), stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.call("dvsg_conv_gemm_f32", x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y.data_ptr(), B, H, W, cin, cout, k,
+        _lib.call(FN, x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y.data_ptr(), B, H, W, cin, cout, k,
                   1, 1, 1, scratch.data_ptr(), scratch.numel(), stream)
         e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3
