@@ -618,14 +618,16 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
     // less than one round) as equal shares of (tile, K-stage) units
     d.tile_begin = tiles - streamk_tail;
     d.tile_count = streamk_tail;
-    if (SPLIT && g_conv_variant == 8) return launch_cfg<T, 128, 2, 2, KS, 2, SPLIT>(d, d.tile_begin + kResident, relu, res, s);
     return launch_cfg<T, 128, 2, 4, KS, 2, SPLIT>(d, d.tile_begin + kResident, relu, res, s);
   }
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
   // waves in flight.  (A 4-stage LDS-DMA ring, 96 KB of LDS and one workgroup per CU, was measured
   // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.)
-  const bool four = g_conv_variant == 1 || g_conv_variant == 8 || ((g_conv_variant == 0 || g_conv_variant == 6) && tiles <= 512);
+  // f32s (SPLIT, float): a tile's matrix-core time is a fifth of the exact path's, so the 4 fat waves win at every
+  // tile count -- half the fragment reads per MFMA -- (measured per layer, tools/conv_bench.py --precision f32s)
+  const bool four = g_conv_variant == 1 || (SPLIT && sizeof(T) == 4 && g_conv_variant == 0) ||
+                    ((g_conv_variant == 0 || g_conv_variant == 6) && tiles <= 512);
   if (four)
     return wide ? launch_cfg<T, 128, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s)
                 : launch_cfg<T, 64, 2, 2, KS, 0, SPLIT>(d, tiles, relu, res, s);
@@ -669,7 +671,7 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   const long tiles128 = split ? (long)d.mtiles * (p.Cout / 64) : p.Cout % 128 == 0 ? (long)d.mtiles * (p.Cout / 128) : 0;
   const int kt_all = d.K / bke;
   const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
-  const bool streamk_ok = (g_conv_variant == 0 || g_conv_variant == 8) && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes && res == 0;
+  const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes && res == 0;
   const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
   const bool wide = split || (g_conv_variant != 4 && (tiles128 >= kResident || streamk_all));
   d.ntiles = split ? p.Cout / 64 : p.Cout / (wide ? 128 : 64);
@@ -702,7 +704,10 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   int streamk_tail = 0;
   if (streamk_all) {
     streamk_tail = (int)tiles;
-  } else if (streamk_ok && wide && d.ksplit == 1 && tiles > kResident) {
+  } else if (streamk_ok && wide && d.ksplit == 1 && tiles > kResident && !psplit) {
+    // (f32s: with tiles five times cheaper in matrix-core time the partial-tile traffic of a tail costs more
+    // than the tail it removes: 103 vs 142 us on block 3's 1024 -> 256 layers; only a launch that is less
+    // than one round, above, still pays)
     const int r = (int)(tiles % kResident);
     if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 32 && (long)r * kt_all >= 2L * kResident) streamk_tail = r;
   }
