@@ -61,6 +61,9 @@ struct ConvFused {
   const float *sc_wt = nullptr;
   const float *sc_bias = nullptr;
   int sc_cin = 0;
+  // "f32s": x, res / sc_x, y hold float16 pieces (P format) and wt2, wt3, sc_wt are the layers' piece matrices
+  // ([rows][K/32][32 hi | 32 lo]); same bytes per value, same addressing (pass them through the float pointers)
+  int pieces = 0;
 };
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize);
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s);

@@ -53,7 +53,44 @@ struct ConvFusedDev {
 
 constexpr int CSC = 64;     // RES == 3: channels of the shortcut's input (block 1: the pooled conv1 output)
 
-template <int RES>  // 1: residual has the output's shape, 2: subsampled shortcut x[:, ::s, ::s, :], 3: shortcut conv fused
+// One 32-k stage of A-row x B-row products into `acc`: exact float32 (four 16-byte chunks, 16 MFMAs of
+// 32x32x2) or, PS ("f32s": both rows hold float16 pieces, 32 hi halves then 32 lo halves), two 16-k steps
+// of three 32x32x16 float16 MFMAs -- a1 w1 + a2 w1 + a1 w2 (conv_gemm.hip).
+template <bool PS, int NI>
+__device__ __forceinline__ void stage_mma(const char *a_row, const char *b_row, int sw, int h, floatx16 (&acc)[NI]) {
+  if constexpr (PS) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int g = 2 * t + h;
+      const halfx8 ahi = *reinterpret_cast<const halfx8 *>(a_row + 16 * (g ^ sw));
+      const halfx8 alo = *reinterpret_cast<const halfx8 *>(a_row + 16 * ((4 + g) ^ sw));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const halfx8 bhi = *reinterpret_cast<const halfx8 *>(b_row + ni * 32 * ROWB + 16 * (g ^ sw));
+        const halfx8 blo = *reinterpret_cast<const halfx8 *>(b_row + ni * 32 * ROWB + 16 * ((4 + g) ^ sw));
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[ni], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int co = 16 * ((2 * kb + h) ^ sw);
+      const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_row + co);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_row + ni * 32 * ROWB + co);
+        acc[ni] = Frag<float>::mma(a4, b4, acc[ni]);
+      }
+    }
+  }
+}
+
+// RES: 1 residual has the output's shape, 2 subsampled shortcut x[:, ::s, ::s, :], 3 shortcut conv fused.
+// PS ("f32s" precision): every tensor and weight matrix holds float16 pieces in 128-byte groups (cnn_device.h,
+// conv_gemm.hip): the staging is byte for byte the float32 kernel's, the products come from the f16 matrix cores.
+template <int RES, bool PS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void conv3x3_1x1_kernel(ConvFusedDev p) {
   constexpr int NW = 8;
@@ -119,16 +156,7 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
       asm volatile("" ::: "memory");
       const char *a_base = lds + (step & 1) * 16384 + (wm * 32 + r) * ROWB;
       const char *b_base = lds + 32768 + (step & 1) * 16384 + (wn * 64 + r) * ROWB;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const int co = 16 * ((2 * kb + h) ^ sw);
-        const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_base + co);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_base + ni * 32 * ROWB + co);
-          acc_sc[step >> 1][ni] = Frag<float>::mma(a4, b4, acc_sc[step >> 1][ni]);
-        }
-      }
+      stage_mma<PS, 2>(a_base, b_base, sw, h, acc_sc[step >> 1]);
       if (step < 2) {  // the buffer just read takes the piece two steps ahead
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -188,19 +216,14 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
       }
     }
   };
-  floatx16 acc1;
+  floatx16 acc1v[1];
+  floatx16 &acc1 = acc1v[0];
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
   auto compute_stage = [&](int buf) __attribute__((always_inline)) {
     const char *a_base = As + (buf * BM + wm * 32 + r) * ROWB;
     const char *b_base = Bs + (buf * CMID + wn * 32 + r) * ROWB;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int co = 16 * ((2 * kb + h) ^ sw);
-      const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_base + co);
-      const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_base + co);
-      acc1 = Frag<float>::mma(a4, b4, acc1);
-    }
+    stage_mma<PS, 1>(a_base, b_base, sw, h, acc1v);
   };
   auto w3_issue = [&](int half, int s2) __attribute__((always_inline)) {
     // conv3 weight rows n = 128 half + row, 32-k stage s2: stage 0 -> lds + 48 KiB, stage 1 -> lds + 32 KiB
@@ -242,7 +265,14 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
   for (int q = 0; q < 16; ++q) {
     const int R = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
     const float v = fmaxf(acc1[q] + bmid, 0.f);
-    *reinterpret_cast<float *>(lds + (wn * BM + R) * ROWB + 16 * ((r >> 2) ^ ((R >> 1) & 7)) + 4 * (r & 3)) = v;
+    if (PS) {  // the value's two float16 pieces: hi in 16-byte chunk r / 8 of the row, lo in chunk 4 + r / 8
+      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+      char *row = lds + (wn * BM + R) * ROWB + 2 * (r & 7);
+      *reinterpret_cast<_Float16 *>(row + 16 * ((r >> 3) ^ ((R >> 1) & 7))) = hi;
+      *reinterpret_cast<_Float16 *>(row + 16 * ((4 + (r >> 3)) ^ ((R >> 1) & 7))) = lo;
+    } else {
+      *reinterpret_cast<float *>(lds + (wn * BM + R) * ROWB + 16 * ((r >> 2) ^ ((R >> 1) & 7)) + 4 * (r & 3)) = v;
+    }
   }
   w3_issue(0, 1);
 
@@ -254,19 +284,10 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  auto compute2 = [&](int s2, floatx16 *acc2) __attribute__((always_inline)) {
+  auto compute2 = [&](int s2, floatx16 (&acc2)[2]) __attribute__((always_inline)) {
     const char *a_base = lds + (s2 * BM + wm * 32 + r) * ROWB;
     const char *b_base = lds + (s2 == 0 ? 49152 : 32768) + (wn * 64 + r) * ROWB;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int co = 16 * ((2 * kb + h) ^ sw);
-      const floatx4 a4 = *reinterpret_cast<const floatx4 *>(a_base + co);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const floatx4 b4 = *reinterpret_cast<const floatx4 *>(b_base + ni * 32 * ROWB + co);
-        acc2[ni] = Frag<float>::mma(a4, b4, acc2[ni]);
-      }
-    }
+    stage_mma<PS, 2>(a_base, b_base, sw, h, acc2);
   };
   // one 128-channel half of the output: conv3 on top of `acc2` (zeros, or the half's shortcut tile)
   const int nhalves = p.Cout / 128;
@@ -304,7 +325,7 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
             const int b = t / p.Ho;
             roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
           }
-          rv[i] = load4(p.res + roff);
+          rv[i] = PS ? load4_p(p.res, roff) : load4(p.res + roff);
         }
       }
       lds_barrier();  // weights of this half consumed / previous round's rows read
@@ -333,7 +354,8 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
             v.z = fmaxf(v.z + bias4.z + rv[i].z, 0.f);
             v.w = fmaxf(v.w + bias4.w + rv[i].w, 0.f);
           }
-          store4(p.y + (size_t)m * p.Cout + n, v);
+          if (PS) store4_p(p.y, (size_t)m * p.Cout + n, v);
+          else store4(p.y + (size_t)m * p.Cout + n, v);
         }
       }
     }
@@ -364,7 +386,7 @@ int g_fuse_conv = 1;  // dvsg_debug_set_option("fuse_conv", 0) turns the fused b
 
 void set_fuse_conv(int v) { g_fuse_conv = v; }
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize) {
-  return g_fuse_conv != 0 && prec == kF32 && ksize == 3 && Cmid == CMID && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0;
+  return g_fuse_conv != 0 && (prec == kF32 || prec == kF32S) && ksize == 3 && Cmid == CMID && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0;
 }
 
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
@@ -391,12 +413,16 @@ int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
                  2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID + (sc ? 2.0 * (double)M * p.Cout * CSC : 0.0),
                  4.0 * ((double)p.B * p.H * p.W * p.Cin + (double)CMID * 9 * p.Cin + (double)p.Cout * CMID +
                         (sc ? (double)M * CSC + (double)p.Cout * CSC + (double)M * p.Cout : 2.0 * (double)M * p.Cout)));
-  if (res == 1)
-    hipLaunchKernelGGL(conv3x3_1x1_kernel<1>, dim3(d.mtiles), dim3(512), 0, s, d);
-  else if (res == 2)
-    hipLaunchKernelGGL(conv3x3_1x1_kernel<2>, dim3(d.mtiles), dim3(512), 0, s, d);
-  else
-    hipLaunchKernelGGL(conv3x3_1x1_kernel<3>, dim3(d.mtiles), dim3(512), 0, s, d);
+  const dim3 grid(d.mtiles), block(512);
+  if (p.pieces) {
+    if (res == 1) hipLaunchKernelGGL((conv3x3_1x1_kernel<1, true>), grid, block, 0, s, d);
+    else if (res == 2) hipLaunchKernelGGL((conv3x3_1x1_kernel<2, true>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((conv3x3_1x1_kernel<3, true>), grid, block, 0, s, d);
+  } else {
+    if (res == 1) hipLaunchKernelGGL((conv3x3_1x1_kernel<1>), grid, block, 0, s, d);
+    else if (res == 2) hipLaunchKernelGGL((conv3x3_1x1_kernel<2>), grid, block, 0, s, d);
+    else hipLaunchKernelGGL((conv3x3_1x1_kernel<3>), grid, block, 0, s, d);
+  }
   return check_launch("conv3x3_1x1_kernel");
 }
 

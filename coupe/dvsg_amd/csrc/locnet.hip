@@ -366,13 +366,16 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
     DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
     if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
-      f.x = reinterpret_cast<const float *>(ws.r1); f.wt2 = u.c2.wt; f.bias2 = u.c2.bias; f.wt3 = u.c3.wt; f.bias3 = u.c3.bias;
+      const bool pcs = prec == kF32S;
+      auto wts_of = [&](const ConvLayer &L) { return pcs ? reinterpret_cast<const float *>(L.wt32s) : L.wt; };
+      f.pieces = pcs;
+      f.x = reinterpret_cast<const float *>(ws.r1); f.wt2 = wts_of(u.c2); f.bias2 = u.c2.bias; f.wt3 = wts_of(u.c3); f.bias3 = u.c3.bias;
       f.res = static_cast<const float *>(res); f.y = reinterpret_cast<float *>(Y);
       f.B = B; f.H = h; f.W = w; f.Cin = u.c2.cin; f.Ho = ho; f.Wo = wo; f.Cout = u.c3.cout;
       f.stride = u.c2.stride; f.res_H = res_h; f.res_W = res_w; f.res_stride = res_stride;
       if (fuse_sc) {
         f.res = nullptr;
-        f.sc_x = reinterpret_cast<const float *>(X); f.sc_wt = u.shortcut.wt; f.sc_bias = u.shortcut.bias;
+        f.sc_x = reinterpret_cast<const float *>(X); f.sc_wt = wts_of(u.shortcut); f.sc_bias = u.shortcut.bias;
         f.sc_cin = u.shortcut.cin;
       }
       DVSG_RUN(launch_conv3x3_1x1(f, s));
