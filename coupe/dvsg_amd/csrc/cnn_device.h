@@ -69,6 +69,45 @@ __device__ __forceinline__ void store4_p(void *base, size_t e, float4 v) {
   *reinterpret_cast<halfx4 *>(q + 64) = lo;
 }
 
+// The same for a PAIR of adjacent lanes that hold channels [n, n+4) (even lane) and [n+4, n+8) (odd lane) of one
+// pixel, n % 8 == 0 (every epilogue's thread map): the lanes swap one 8-byte half through a quad-permute DPP move
+// so that the even lane moves the 16 bytes of hi pieces of all 8 channels and the odd lane the 16 bytes of lo
+// pieces -- one 16-byte memory instruction per lane, like a float32 float4, instead of two 8-byte ones.
+// `e` is the lane's OWN flat element index (channel n or n + 4).  All 64 lanes must be active.
+__device__ __forceinline__ unsigned dpp_swap1(unsigned v) {  // value of lane ^ 1
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void store4_p_pair(void *base, size_t e, float4 v, bool odd, bool guard) {
+  halfx4 hi, lo;
+  hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+  lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+  lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+  typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+  const uintx2 h2 = __builtin_bit_cast(uintx2, hi), l2 = __builtin_bit_cast(uintx2, lo);
+  // even lane gives its lo and gets the odd lane's hi; odd lane gives its hi and gets the even lane's lo
+  const uintx2 give = odd ? h2 : l2;
+  const uintx2 got = {dpp_swap1(give[0]), dpp_swap1(give[1])};
+  const uintx4 out = odd ? uintx4{got[0], got[1], l2[0], l2[1]} : uintx4{h2[0], h2[1], got[0], got[1]};
+  const size_t e8 = e & ~(size_t)7;  // the pair's first channel
+  char *q = static_cast<char *>(base) + (e8 >> 5) * 128 + (e8 & 31) * 2 + (odd ? 64 : 0);
+  if (guard) *reinterpret_cast<uintx4 *>(q) = out;
+}
+__device__ __forceinline__ float4 load4_p_pair(const void *base, size_t e, bool odd) {
+  typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+  typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+  const size_t e8 = e & ~(size_t)7;
+  const char *q = static_cast<const char *>(base) + (e8 >> 5) * 128 + (e8 & 31) * 2 + (odd ? 64 : 0);
+  const uintx4 in = *reinterpret_cast<const uintx4 *>(q);  // even: hi of 8 channels; odd: lo of 8 channels
+  // even keeps hi[0..3] and needs lo[0..3] (the odd lane's first half); odd keeps lo[4..7] and needs hi[4..7]
+  const uintx2 give = odd ? uintx2{in[0], in[1]} : uintx2{in[2], in[3]};
+  const uintx2 got = {dpp_swap1(give[0]), dpp_swap1(give[1])};
+  const halfx4 hi = __builtin_bit_cast(halfx4, odd ? got : uintx2{in[0], in[1]});
+  const halfx4 lo = __builtin_bit_cast(halfx4, odd ? uintx2{in[2], in[3]} : got);
+  return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2],
+                     (float)hi[3] + (float)lo[3]);
+}
+
 // Four consecutive channels of an activation tensor <-> float4.
 __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 load4(const _Float16 *p) {

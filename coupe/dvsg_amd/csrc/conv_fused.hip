@@ -325,7 +325,7 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
             const int b = t / p.Ho;
             roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
           }
-          rv[i] = PS ? load4_p(p.res, roff) : load4(p.res + roff);
+          rv[i] = PS ? load4_p_pair(p.res, roff, col4 & 1) : load4(p.res + roff);
         }
       }
       lds_barrier();  // weights of this half consumed / previous round's rows read
@@ -354,7 +354,7 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
             v.z = fmaxf(v.z + bias4.z + rv[i].z, 0.f);
             v.w = fmaxf(v.w + bias4.w + rv[i].w, 0.f);
           }
-          if (PS) store4_p(p.y, (size_t)m * p.Cout + n, v);
+          if (PS) store4_p_pair(p.y, (size_t)m * p.Cout + n, v, col4 & 1, true);
           else store4(p.y + (size_t)m * p.Cout + n, v);
         }
       }

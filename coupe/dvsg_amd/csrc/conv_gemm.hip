@@ -353,7 +353,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
           const int b = t / p.Ho;
           roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
         }
-        rv[i] = PSPLIT ? load4_p(p.res, roff) : load4(pres + roff);
+        rv[i] = PSPLIT ? load4_p_pair(p.res, roff, col4 & 1) : load4(pres + roff);
       }
     };
     DVSG_STAMP(1);
@@ -496,7 +496,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
             const int b = t / p.Ho;
             roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
           }
-          r4 = PSPLIT ? load4_p(p.res, roff) : load4(pres + roff);
+          r4 = PSPLIT ? load4_p_pair(p.res, roff, col4 & 1) : load4(pres + roff);
         } else {
           r4 = rv[i];
         }
@@ -505,7 +505,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       if (RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      if (PSPLIT) store4_p(p.y, (size_t)m * p.Cout + n, v);
+      if (PSPLIT) store4_p_pair(p.y, (size_t)m * p.Cout + n, v, col4 & 1, true);  // lanes 2j, 2j+1: one pixel, 8 channels
       else store4(py + (size_t)m * p.Cout + n, v);
     }
   };
@@ -672,7 +672,9 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   const int kt_all = d.K / bke;
   const size_t streamk_need = (size_t)kResident * 2 * BM * 128 * sizeof(float);
   const bool streamk_ok = g_conv_variant == 0 && p.splitk_scratch && streamk_need <= p.splitk_scratch_bytes && res == 0;
-  const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= 32;
+  // (f32s: only for the very long K loops -- block 4's 3x3 layers; 1024- and 2048-deep 1x1 layers of 460 tiles run
+  // 52 vs 87 us and 96 vs 157 us without it)
+  const bool streamk_all = streamk_ok && tiles128 >= kResident / 2 && tiles128 < kResident && kt_all >= (psplit ? 128 : 32);
   const bool wide = split || (g_conv_variant != 4 && (tiles128 >= kResident || streamk_all));
   d.ntiles = split ? p.Cout / 64 : p.Cout / (wide ? 128 : 64);
   // Tile order.  Each XCD runs a contiguous range of tiles.  With nt fastest that range covers every
