@@ -380,7 +380,7 @@ def main():
         if cls in MFMA_CLASSES:
             achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
             # f32s: three float16 MFMAs per float32-equivalent product; f16: two (hi / lo weights), priced on algorithmic FLOPs
-            peak = (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" or cls == 0 else
+            peak = (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else
                     PEAK_F16_MFMA_TFLOPS / 3.0 if args.precision == "f32s" else PEAK_F16_MFMA_TFLOPS)
             roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
         else:
