@@ -1,11 +1,14 @@
 // Launch interface of the localizationNet kernels (conv_gemm.hip, conv1_pool.hip, head.hip),
 // used by locnet.hip.
 //
-// Two storage precisions share every kernel through a template parameter:
-//   kF32  float32 activations / weights, exact-f32 matrix cores (v_mfma_f32_32x32x2_f32)
-//   kF16  float16 activations / weights, v_mfma_f32_32x32x16_f16 with float32 accumulation;
-//         conv1 still multiplies in f32 (its input is the reference's float32 frames) and
-//         writes f16; bias, accumulators and the dense head stay float32.
+// Three precisions share the kernels through template parameters:
+//   kF32   float32 activations / weights, exact-f32 matrix cores (v_mfma_f32_32x32x2_f32): the path of record
+//   kF32S  4 bytes per value and float32 accumulation, but every operand enters the float16 matrix cores as two
+//          float16 pieces (22 significant bits) and the activation tensors between layers hold those pieces;
+//          values must stay inside float16's range (|x| < 65504), which post-BatchNorm activations and BN-folded
+//          weights do by orders of magnitude
+//   kF16   float16 activations, conv weights as float16 hi / lo pairs, v_mfma_f32_32x32x16_f16 with float32
+//          accumulation; bias, accumulators and the dense head stay float32.
 #pragma once
 #include "common.h"
 

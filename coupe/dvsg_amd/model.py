@@ -63,7 +63,10 @@ class StabNet:
         self.param_dim = self.num_control_points ** 2
         self.stabNet_model = 'resnet_v1_50'
         self.n_streams = 1   # 2 = batch halves on two HIP streams (LocNet.stabilize): <1 % at B=16 720p
-        self.precision = "f32"   # "f16": float16 activations / conv weights in localizationNet
+        # "f32": exact float32 matrix cores (the reference's arithmetic, the path of record); "f32s": float32 width and
+        # accumulation, products from two float16 pieces per operand (2x faster, float32-GEMM-level differences);
+        # "f16": float16 activations, hi / lo float16 conv weights
+        self.precision = "f32"
         self.locnet = None
         self.inputs = None
         self.outputs = None

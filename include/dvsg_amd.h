@@ -206,7 +206,9 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
  * exact path: stage activations within 2e-6 relative, F_t within 1e-7, i.e. what two float32 GEMMs with
  * different summation orders differ by; every float32 parity test of tests/ also passes in this mode
  * (tests/test_gpu_f32s.py).  It is NOT the exact float32 arithmetic of the reference and is therefore a
- * separately named precision; dvsg_*_f32 stays the path of record.
+ * separately named precision; dvsg_*_f32 stays the path of record.  Values must stay inside float16's range
+ * (|x| < 65504; beyond it a piece is infinite), which BatchNorm-folded weights and post-BatchNorm activations
+ * do by orders of magnitude.
  * ------------------------------------------------------------------------------------- */
 int dvsg_locnet_forward_f32s(const dvsg_locnet_t *net, const float *patches, int B, int H, int W,
                              float *F_t, void *workspace, size_t workspace_bytes, void *stream);
