@@ -706,10 +706,11 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   int streamk_tail = 0;
   if (streamk_all) {
     streamk_tail = (int)tiles;
-  } else if (streamk_ok && wide && d.ksplit == 1 && tiles > kResident && !psplit) {
-    // (f32s: with tiles five times cheaper in matrix-core time the partial-tile traffic of a tail costs more
-    // than the tail it removes: 103 vs 142 us on block 3's 1024 -> 256 layers; only a launch that is less
-    // than one round, above, still pays)
+  } else if (streamk_ok && wide && d.ksplit == 1 && tiles > kResident && !psplit && !split) {
+    // (f32s, and the float16 mode with its hi / lo weights: with tiles several times cheaper in matrix-core time
+    // the partial-tile traffic of a tail costs more than the tail it removes -- f32s: 103 vs 142 us on block 3's
+    // 1024 -> 256 layers, f16: +2.4 % end to end at 720p without it; only a launch that is less than one round,
+    // above, still pays)
     const int r = (int)(tiles % kResident);
     if (r > 0 && r <= kResident * 4 / 5 && kt_all >= 32 && (long)r * kt_all >= 2L * kResident) streamk_tail = r;
   }
