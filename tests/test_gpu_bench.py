@@ -33,6 +33,9 @@ def test_bench_line_has_the_contract_fields():
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    assert c["cpu_model"] and c["cnn_ms_per_frame"] > 0 and c["warp_ms_per_frame"] > 0
+    s2 = d["secondary"]      # the f32s rate, beside the line of record and outside its timed region
+    assert s2["precision"] == "f32s" and s2["dtype"] == "f32x2f16" and s2["value"] > 0
 
 
 def test_bench_other_kernel_classes_and_precision():
@@ -40,6 +43,12 @@ def test_bench_other_kernel_classes_and_precision():
              "--no-cpu-baseline", "--precision", "f16")
     assert d["dtype"] == "f16" and d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s"
     assert "cpu_baseline" not in d
+
+
+def test_bench_f32s_precision_is_separately_named():
+    d = _run("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "96", "--width", "160", "--precision", "f32s",
+             "--no-cpu-baseline")
+    assert d["dtype"] == "f32x2f16" and "secondary" not in d and d["roofline"]["peak"] == pytest.approx(2500.0 / 3.0)
 
 
 def test_bench_tf_warp_workload():
