@@ -426,8 +426,8 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   __shared__ __attribute__((aligned(16))) unsigned in_hi[C1S_SEG / 2], in_lo[C1S_SEG / 2];  // half2 per word
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  const int r = lane & 31, h = lane >> 5;   // wave w: pixels [32 w, 32 w + 32) x all 64 channels (two 32-channel blocks):
+                                            // an activation fragment is read once for both blocks (the LDS is this kernel's bound)
 
   int blk = xcd_remap(blockIdx.x, gridDim.x);  // see conv1_kernel
   const int wt_i = blk % wtiles;
@@ -496,11 +496,11 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     }
   };
 
-  floatx16 acc[2], accl[2];
+  floatx16 acc[2], accl[2];   // [channel block]
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[mi][q] = accl[mi][q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[ni][q] = accl[ni][q] = 0.f;
 
   load_stage(0);
   for (int kh = 0; kh < 7; ++kh) {
@@ -510,31 +510,27 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     if (kh + 1 < 7) load_stage(kh + 1);
     __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
     // word index of the lane's first tap pair: (42 pixel + 8 h) / 2
-    const int a0 = kConv1Cin * (wm * 64 + r) + 4 * h;
-    const _Float16 *bhi0 = reinterpret_cast<const _Float16 *>(w_s) + (wn * 32 + r) * kConv1LdH + 8 * h;
+    const int a0 = kConv1Cin * (wave * 32 + r) + 4 * h;
+    const _Float16 *bhi0 = reinterpret_cast<const _Float16 *>(w_s) + r * kConv1LdH + 8 * h;
     const _Float16 *blo0 = bhi0 + 64 * kConv1LdH;
 #pragma unroll 2
     for (int t = 0; t < 10; ++t) {
       union {
         unsigned u[4];
         halfx8 v;
-      } ahi[2], alo[2];
+      } ahi, alo;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int w0 = a0 + mi * (kConv1Cin * 32) + 8 * t;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ahi[mi].u[j] = in_hi[w0 + j];
-          alo[mi].u[j] = in_lo[w0 + j];
-        }
+      for (int j = 0; j < 4; ++j) {
+        ahi.u[j] = in_hi[a0 + 8 * t + j];
+        alo.u[j] = in_lo[a0 + 8 * t + j];
       }
-      const halfx8 bhi = *reinterpret_cast<const halfx8 *>(bhi0 + 16 * t);
-      const halfx8 blo = *reinterpret_cast<const halfx8 *>(blo0 + 16 * t);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi].v, bhi, acc[mi], 0, 0, 0);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi].v, bhi, acc[mi], 0, 0, 0);
-        accl[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi].v, blo, accl[mi], 0, 0, 0);
+      for (int ni = 0; ni < 2; ++ni) {
+        const halfx8 bhi = *reinterpret_cast<const halfx8 *>(bhi0 + ni * 32 * kConv1LdH + 16 * t);
+        const halfx8 blo = *reinterpret_cast<const halfx8 *>(blo0 + ni * 32 * kConv1LdH + 16 * t);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi.v, bhi, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo.v, bhi, acc[ni], 0, 0, 0);
+        accl[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi.v, blo, accl[ni], 0, 0, 0);
       }
     }
   }
@@ -543,10 +539,10 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   float *Cs = reinterpret_cast<float *>(w_s);
   __syncthreads();
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      Cs[(wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + wn * 32 + r] = acc[mi][q] + accl[mi][q] * (1.0f / 2048.0f);
+      Cs[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + ni * 32 + r] = acc[ni][q] + accl[ni][q] * (1.0f / 2048.0f);
   __syncthreads();
   const int col4 = tid & 15, row0 = tid >> 4;
   const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
