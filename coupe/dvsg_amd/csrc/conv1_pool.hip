@@ -410,12 +410,12 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
 // Ten 16-tap steps per kernel row (147 taps padded to 160 with zero weights): 60 MFMAs of 32 cycles per
 // wave and kernel row where the exact kernel issues 150 of 64.
 // ----------------------------------------------------------------------------------------
-constexpr int C1S_SEG = 5504;                        // halves per staged image of the row (5481 + zero tail; reads reach 5494)
-constexpr int C1S_INPAIRS = (C1S_SEG / 2 + 255) / 256;  // 11 pairs per thread
+constexpr int C1S_SEG = 5504;                        // halves per staged image of the row (1 + 5481 + tail; reads reach 5495)
+constexpr int C1S_IN4 = (C1S_SEG / 4 + 255) / 256;     // 6 groups of four elements per thread
 constexpr int C1S_WHALFS = 2 * 64 * kConv1LdH;       // halves per kernel row: hi image, then lo image
 constexpr int C1S_WBYTES = C1S_WHALFS * 2;           // 43008
 
-template <typename TO>
+template <typename TO, bool ALIGNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1s, const float *__restrict__ bias,
                         TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
@@ -436,24 +436,35 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
+  // The row segment is fetched as 16-byte groups of four consecutive elements, 6 loads per thread and kernel
+  // row where element-wise fetching issued 22, and two 8-byte LDS writes per group and image.  The segment
+  // starts one element before the first window (the weights carry a zero tap in front), which puts it on a
+  // multiple of four elements of the row: when the rows themselves are 16-byte aligned (ALIGNED: W a multiple
+  // of 4) every group is inside the row or outside it as a whole and the loads are unconditional and aligned.
+  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
+  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[2 * C1S_INPAIRS];
-  int idx_i[2 * C1S_INPAIRS];
-  unsigned col_ok = 0;
+  float mean_i[4 * C1S_IN4];
+  long idx_i[C1S_IN4];
+  unsigned col_ok = 0, full = 0;
 #pragma unroll
-  for (int i = 0; i < 2 * C1S_INPAIRS; ++i) {
-    const int e = 2 * (tid + NT * (i >> 1)) + (i & 1);
-    const long ge = seg0 + e;
-    const int c = e % kConv1Cin;
-    const int g = c / (kConv1Cin / 3);
-    mean_i[i] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
-    const bool ok = e < C1_SEG && ge >= 0 && ge < row_elems;
-    if (ok) col_ok |= 1u << i;
-    idx_i[i] = ok ? (int)ge : 0;
+  for (int i = 0; i < C1S_IN4; ++i) {
+    const int e0 = 4 * (tid + NT * i);
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      const long ge = seg0 + e;
+      const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);   // element e is channel (e - 1) mod 21 of its pixel
+      mean_i[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+      if (e < C1S_SEG && ge >= 0 && ge < row_elems) m |= 1u << j;
+    }
+    col_ok |= m << (4 * i);
+    if (m == 15u) full |= 1u << i;
+    idx_i[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;
   }
 
-  float in_reg[2 * C1S_INPAIRS];
+  floatx4 in_reg[C1S_IN4];
   floatx4 w_reg[WLOADS];
   bool row_ok = false;
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
@@ -462,7 +473,16 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = x + ((long)b * H + hc) * row_elems;
 #pragma unroll
-    for (int i = 0; i < 2 * C1S_INPAIRS; ++i) in_reg[i] = xrow[idx_i[i]];
+    for (int i = 0; i < C1S_IN4; ++i) {
+      if constexpr (ALIGNED) {
+        in_reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx_i[i]);   // a group outside the row reads the row's first
+      } else if ((full >> i) & 1u) {
+        in_reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx_i[i]);
+      } else {   // a group that straddles the row's ends: element by element
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in_reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx_i[i] + j] : 0.f;
+      }
+    }
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1s + (size_t)kh * C1S_WHALFS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -471,22 +491,22 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     }
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
-    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     const unsigned ok = row_ok ? col_ok : 0u;
 #pragma unroll
-    for (int i = 0; i < C1S_INPAIRS; ++i) {
+    for (int i = 0; i < C1S_IN4; ++i) {
       const int q = tid + NT * i;
-      // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops: -ffp-contract=off), then the two pieces
-      const float v0 = ((ok >> (2 * i)) & 1u) ? in_reg[2 * i] * 255.0f - mean_i[2 * i] : 0.f;
-      const float v1 = ((ok >> (2 * i + 1)) & 1u) ? in_reg[2 * i + 1] * 255.0f - mean_i[2 * i + 1] : 0.f;
-      half2_t hv, lv;
-      hv[0] = (_Float16)v0;
-      hv[1] = (_Float16)v1;
-      lv[0] = (_Float16)(v0 - (float)hv[0]);
-      lv[1] = (_Float16)(v1 - (float)hv[1]);
-      if (q < C1S_SEG / 2) {
-        in_hi[q] = __builtin_bit_cast(unsigned, hv);
-        in_lo[q] = __builtin_bit_cast(unsigned, lv);
+      half4_t hv, lv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops: -ffp-contract=off), then the two pieces
+        const float v = ((ok >> (4 * i + j)) & 1u) ? in_reg[i][j] * 255.0f - mean_i[4 * i + j] : 0.f;
+        hv[j] = (_Float16)v;
+        lv[j] = (_Float16)(v - (float)hv[j]);
+      }
+      if (q < C1S_SEG / 4) {
+        reinterpret_cast<half4_t *>(in_hi)[q] = hv;
+        reinterpret_cast<half4_t *>(in_lo)[q] = lv;
       }
     }
 #pragma unroll
@@ -604,8 +624,12 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1
                  4.0 * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
   const dim3 grid((unsigned)blocks);
   if (out_prec == kF32S && wt1s && g_conv1_variant != 2) {
-    hipLaunchKernelGGL((conv1_split_kernel<float>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s), bias,
-                       static_cast<float *>(y), H, W, Ho, Wo, wtiles);
+    if (W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+      hipLaunchKernelGGL((conv1_split_kernel<float, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
+                         bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
+    else
+      hipLaunchKernelGGL((conv1_split_kernel<float, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
+                         bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
   } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
     hipLaunchKernelGGL((conv1_f16_kernel<_Float16>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
                        bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);

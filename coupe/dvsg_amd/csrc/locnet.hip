@@ -188,15 +188,16 @@ int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Co
     for (int n = 0; n < 64; ++n)
       for (int k = 0; k < kConv1K; ++k)
         wth[((size_t)kh * 64 + n) * kConv1LdH + k] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k];
-  // "f32s" pieces, [7][2][64][kConv1LdH]: hi image then lo image per kernel row, lo scaled by 2^11 (conv1_split_kernel)
+  // "f32s" pieces, [7][2][64][kConv1LdH]: hi image then lo image per kernel row, lo scaled by 2^11; tap k sits at
+  // k + 1 behind a zero tap (conv1_split_kernel stages the input row from one element before the window)
   std::vector<_Float16> wts((size_t)7 * 2 * 64 * kConv1LdH, (_Float16)0.f);
   for (int kh = 0; kh < 7; ++kh)
     for (int n = 0; n < 64; ++n)
       for (int k = 0; k < kConv1K; ++k) {
         const float w32 = wt[((size_t)kh * 64 + n) * kConv1Ld + k];
         const _Float16 hi = (_Float16)w32;
-        wts[(((size_t)kh * 2 + 0) * 64 + n) * kConv1LdH + k] = hi;
-        wts[(((size_t)kh * 2 + 1) * 64 + n) * kConv1LdH + k] = (_Float16)((w32 - (float)hi) * 2048.0f);
+        wts[(((size_t)kh * 2 + 0) * 64 + n) * kConv1LdH + k + 1] = hi;
+        wts[(((size_t)kh * 2 + 1) * 64 + n) * kConv1LdH + k + 1] = (_Float16)((w32 - (float)hi) * 2048.0f);
       }
   if (int rc = upload(net, wt, &L->wt)) return rc;
   if (int rc = upload(net, wth, &L->wt16)) return rc;
