@@ -533,25 +533,41 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
     const int a0 = kConv1Cin * (wave * 32 + r) + 4 * h;
     const _Float16 *bhi0 = reinterpret_cast<const _Float16 *>(w_s) + r * kConv1LdH + 8 * h;
     const _Float16 *blo0 = bhi0 + 64 * kConv1LdH;
-#pragma unroll 2
-    for (int t = 0; t < 10; ++t) {
+    // software-pipelined: the fragments of step t + 1 are requested before the MFMAs of step t are issued (left to
+    // itself the compiler waits for each pair of steps' reads with nothing in flight)
+    struct Frag {
       union {
         unsigned u[4];
         halfx8 v;
       } ahi, alo;
+      halfx8 bhi[2], blo[2];
+    };
+    auto read_frag = [&](Frag &f, int t) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        ahi.u[j] = in_hi[a0 + 8 * t + j];
-        alo.u[j] = in_lo[a0 + 8 * t + j];
+        f.ahi.u[j] = in_hi[a0 + 8 * t + j];
+        f.alo.u[j] = in_lo[a0 + 8 * t + j];
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const halfx8 bhi = *reinterpret_cast<const halfx8 *>(bhi0 + ni * 32 * kConv1LdH + 16 * t);
-        const halfx8 blo = *reinterpret_cast<const halfx8 *>(blo0 + ni * 32 * kConv1LdH + 16 * t);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi.v, bhi, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo.v, bhi, acc[ni], 0, 0, 0);
-        accl[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi.v, blo, accl[ni], 0, 0, 0);
+        f.bhi[ni] = *reinterpret_cast<const halfx8 *>(bhi0 + ni * 32 * kConv1LdH + 16 * t);
+        f.blo[ni] = *reinterpret_cast<const halfx8 *>(blo0 + ni * 32 * kConv1LdH + 16 * t);
       }
+    };
+    Frag fr[2];
+    read_frag(fr[0], 0);
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      if (t + 1 < 10) read_frag(fr[(t + 1) & 1], t + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that do not need them
+      const Frag &f = fr[t & 1];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi.v, f.bhi[ni], acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.alo.v, f.bhi[ni], acc[ni], 0, 0, 0);
+        accl[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi.v, f.blo[ni], accl[ni], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
