@@ -156,17 +156,34 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
     const float *a0 = in_s + 2 * kConv1Cin * (wm * 32 * MI + r) + 2 * h;
     const float *bp = w_s + (wn * 32 + r) * kConv1Ld + 2 * h;
-#pragma unroll 4
-    for (int u = 0; u < kConv1Kpad / 4; ++u) {
-      float2 va[MI];
+    // software-pipelined: the operands of step u + 1 are requested before the MFMAs of step u are issued (the
+    // compiler's own schedule waits for each step's reads with nothing else in flight)
+    constexpr int STEPS = kConv1Kpad / 4, PAIRS = (STEPS + 1) / 2;   // two steps per request: one ds_read2_b64 per operand
+    float2 va[2][2][MI], vb[2][2];
+    auto read_pair = [&](int slot, int g) __attribute__((always_inline)) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        va[mi] = *reinterpret_cast<const float2 *>(a0 + mi * (2 * kConv1Cin * 32) + 4 * u);
-      const float2 vb = *reinterpret_cast<const float2 *>(bp + 4 * u);
+      for (int j = 0; j < 2; ++j) {
+        if (2 * g + j >= STEPS) break;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32(va[mi].x, vb.x, acc[mi]);
+        for (int mi = 0; mi < MI; ++mi)
+          va[slot][j][mi] = *reinterpret_cast<const float2 *>(a0 + mi * (2 * kConv1Cin * 32) + 4 * (2 * g + j));
+        vb[slot][j] = *reinterpret_cast<const float2 *>(bp + 4 * (2 * g + j));
+      }
+    };
+    read_pair(0, 0);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32(va[mi].y, vb.y, acc[mi]);
+    for (int g = 0; g < PAIRS; ++g) {
+      if (g + 1 < PAIRS) read_pair((g + 1) & 1, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (2 * g + j >= STEPS) break;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32(va[g & 1][j][mi].x, vb[g & 1][j].x, acc[mi]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi] = mfma32(va[g & 1][j][mi].y, vb[g & 1][j].y, acc[mi]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
