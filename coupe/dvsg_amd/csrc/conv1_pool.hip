@@ -290,8 +290,7 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
   char *in_s = lds + 2 * C1H_WBYTES;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  const int r = lane & 31, h = lane >> 5;   // wave w: pixels [32 w, 32 w + 32) x all 64 channels (see conv1_split_kernel)
 
   int blk = xcd_remap(blockIdx.x, gridDim.x);  // see conv1_kernel
   const int wt_i = blk % wtiles;
@@ -351,11 +350,11 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
     }
   };
 
-  floatx16 acc[2];
+  floatx16 acc[2];   // [channel block]
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[mi][q] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[ni][q] = 0.f;
 
   load_stage(0, 0);
   store_stage(0);
@@ -364,25 +363,31 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
     const int buf = kh & 1;
     if (kh + 1 < 7) load_stage(kh + 1, buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    const char *a0 = in_s + buf * C1H_SEG * 2 + 2 * (2 * kConv1Cin * (wm * 64 + r) + 8 * h);
-    const char *bp = w_s + buf * C1H_WBYTES + 2 * ((wn * 32 + r) * C1H_LD + 8 * h);
-#pragma unroll 2
-    for (int t = 0; t < C1H_STEPS; ++t) {
+    const unsigned *a0 = reinterpret_cast<const unsigned *>(in_s + buf * C1H_SEG * 2) + kConv1Cin * (wave * 32 + r) + 4 * h;
+    const char *bp = w_s + buf * C1H_WBYTES + 2 * (r * C1H_LD + 8 * h);
+    // software-pipelined one step ahead, like conv1_split_kernel
+    struct Frag {
       union {
         unsigned u[4];
         halfx8 v;
-      } fa[2];
+      } a;
+      halfx8 b[2];
+    };
+    auto read_frag = [&](Frag &f, int t) __attribute__((always_inline)) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const unsigned *pa = reinterpret_cast<const unsigned *>(a0 + mi * (2 * 2 * kConv1Cin * 32) + 32 * t);
-        fa[mi].u[0] = pa[0];
-        fa[mi].u[1] = pa[1];
-        fa[mi].u[2] = pa[2];
-        fa[mi].u[3] = pa[3];
-      }
-      const halfx8 fb = *reinterpret_cast<const halfx8 *>(bp + 32 * t);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0].v, fb, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1].v, fb, acc[1], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) f.a.u[j] = a0[8 * t + j];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) f.b[ni] = *reinterpret_cast<const halfx8 *>(bp + 2 * ni * 32 * C1H_LD + 32 * t);
+    };
+    Frag fr[2];
+    read_frag(fr[0], 0);
+#pragma unroll
+    for (int t = 0; t < C1H_STEPS; ++t) {
+      if (t + 1 < C1H_STEPS) read_frag(fr[(t + 1) & 1], t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t & 1].a.v, fr[t & 1].b[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t & 1].a.v, fr[t & 1].b[1], acc[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (kh + 1 < 7) store_stage(buf ^ 1);
@@ -391,10 +396,10 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
 
   float *Cs = reinterpret_cast<float *>(lds);
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      Cs[(wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + wn * 32 + r] = acc[mi][q];
+      Cs[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + ni * 32 + r] = acc[ni][q];
   __syncthreads();
   const int col4 = tid & 15, row0 = tid >> 4;
   const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
