@@ -82,9 +82,10 @@ constexpr int kConv1Cin = 21;
 constexpr int kConv1K = 7 * kConv1Cin;   // 147 taps per kernel row
 constexpr int kConv1Kpad = 148;          // rounded to the 4-k MFMA step
 constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conflict-free ds_read_b64)
-// wt1h (float16 precision only): the same taps as [7][64][kConv1LdH] float16, rows zero-padded to 160.
+// wt1h (float16 precision only): the same taps as [7][64][kConv1LdH] float16, tap k at k + 1 behind a zero tap (the kernels
+// stage the input row from one element before the window: 16-byte aligned), rows zero-padded to 160.
 constexpr int kConv1LdH = 168;
-// wt1s ("f32s" precision only): float16 pieces [7][2][64][kConv1LdH]: hi = f16(w), lo = f16((w - hi) * 2^11).
+// wt1s ("f32s" precision only): float16 pieces [7][2][64][kConv1LdH], same tap positions: hi = f16(w), lo = f16((w - hi) * 2^11).
 int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const void *wt1s, const float *bias,
                  void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
 

@@ -278,9 +278,9 @@ constexpr int C1H_STEPS = 10;
 constexpr int C1H_LD = 168;                        // halfs per weight row in LDS / global
 constexpr int C1H_WBYTES = 64 * C1H_LD * 2;        // 21504 bytes per kernel row = 21 LDS-DMA pieces
 constexpr int C1H_SEG = 5504;                      // halfs per staged input row (5481 + zero tail)
-constexpr int C1H_INPAIRS = (C1H_SEG / 2 + 255) / 256;  // 11 half2 per thread
+constexpr int C1H_IN4 = (C1H_SEG / 4 + 255) / 256;     // 6 groups of four elements per thread
 
-template <typename TO>
+template <typename TO, bool ALIGNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1h, const float *__restrict__ bias,
                       TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
@@ -299,26 +299,34 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
+  // the row segment starts one element before the first window (zero tap in front of the weights) and is fetched as
+  // 16-byte groups: see conv1_split_kernel
+  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
+  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[2 * C1H_INPAIRS];
-  int idx_i[2 * C1H_INPAIRS];
-  unsigned col_ok = 0;
+  float mean_i[4 * C1H_IN4];
+  long idx_i[C1H_IN4];
+  unsigned col_ok = 0, full = 0;
 #pragma unroll
-  for (int i = 0; i < 2 * C1H_INPAIRS; ++i) {
-    const int e = 2 * (tid + 256 * (i >> 1)) + (i & 1);
-    const long ge = seg0 + e;
-    const int c = e % kConv1Cin;
-    const int g = c / (kConv1Cin / 3);
-    mean_i[i] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
-    const bool ok = e < C1_SEG && ge >= 0 && ge < row_elems;
-    if (ok) col_ok |= 1u << i;
-    idx_i[i] = ok ? (int)ge : 0;
+  for (int i = 0; i < C1H_IN4; ++i) {
+    const int e0 = 4 * (tid + 256 * i);
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      const long ge = seg0 + e;
+      const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);
+      mean_i[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+      if (e < C1H_SEG && ge >= 0 && ge < row_elems) m |= 1u << j;
+    }
+    col_ok |= m << (4 * i);
+    if (m == 15u) full |= 1u << i;
+    idx_i[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;
   }
 
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
-  float in_reg[2 * C1H_INPAIRS];
+  floatx4 in_reg[C1H_IN4];
   bool row_ok = false;
   auto load_stage = [&](int kh, int buf) __attribute__((always_inline)) {
     // weights of kernel row kh: 21 pieces of 1 KiB, piece j by wave j % 4, straight into LDS
@@ -331,22 +339,29 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = x + ((long)b * H + hc) * row_elems;
 #pragma unroll
-    for (int i = 0; i < 2 * C1H_INPAIRS; ++i) in_reg[i] = xrow[idx_i[i]];
+    for (int i = 0; i < C1H_IN4; ++i) {
+      if constexpr (ALIGNED) {
+        in_reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx_i[i]);
+      } else if ((full >> i) & 1u) {
+        in_reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx_i[i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in_reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx_i[i] + j] : 0.f;
+      }
+    }
   };
   auto store_stage = [&](int buf) __attribute__((always_inline)) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     const unsigned ok = row_ok ? col_ok : 0u;
-    unsigned *dst = reinterpret_cast<unsigned *>(in_s + buf * C1H_SEG * 2);
+    half4_t *dst = reinterpret_cast<half4_t *>(in_s + buf * C1H_SEG * 2);
 #pragma unroll
-    for (int i = 0; i < C1H_INPAIRS; ++i) {
+    for (int i = 0; i < C1H_IN4; ++i) {
       const int q = tid + 256 * i;
-      // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops), then one rounding to f16
-      const float v0 = ((ok >> (2 * i)) & 1u) ? in_reg[2 * i] * 255.0f - mean_i[2 * i] : 0.f;
-      const float v1 = ((ok >> (2 * i + 1)) & 1u) ? in_reg[2 * i + 1] * 255.0f - mean_i[2 * i + 1] : 0.f;
-      typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-      half2_t hv;
-      hv[0] = (_Float16)v0;
-      hv[1] = (_Float16)v1;
-      if (q < C1H_SEG / 2) dst[q] = *reinterpret_cast<unsigned *>(&hv);
+      half4_t hv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)   // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops), then one rounding to f16
+        hv[j] = (_Float16)(((ok >> (4 * i + j)) & 1u) ? in_reg[i][j] * 255.0f - mean_i[4 * i + j] : 0.f);
+      if (q < C1H_SEG / 4) dst[q] = hv;
     }
   };
 
@@ -669,8 +684,12 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1
       hipLaunchKernelGGL((conv1_split_kernel<float, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
                          bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
   } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
-    hipLaunchKernelGGL((conv1_f16_kernel<_Float16>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
-                       bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
+    if (W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+      hipLaunchKernelGGL((conv1_f16_kernel<_Float16, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
+                         bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
+    else
+      hipLaunchKernelGGL((conv1_f16_kernel<_Float16, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
+                         bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
   } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output
     hipLaunchKernelGGL((conv1_kernel<4, _Float16>), grid, dim3(256), 0, s, x, wt1, bias,
                        static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);

@@ -187,7 +187,7 @@ int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Co
   for (int kh = 0; kh < 7; ++kh)
     for (int n = 0; n < 64; ++n)
       for (int k = 0; k < kConv1K; ++k)
-        wth[((size_t)kh * 64 + n) * kConv1LdH + k] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k];
+        wth[((size_t)kh * 64 + n) * kConv1LdH + k + 1] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k];   // behind a zero tap, like wts
   // "f32s" pieces, [7][2][64][kConv1LdH]: hi image then lo image per kernel row, lo scaled by 2^11; tap k sits at
   // k + 1 behind a zero tap (conv1_split_kernel stages the input row from one element before the window)
   std::vector<_Float16> wts((size_t)7 * 2 * 64 * kConv1LdH, (_Float16)0.f);
