@@ -76,14 +76,14 @@ void set_conv1_variant(int v);
 
 // conv1: 7x7 stride 2, explicit pad 3, C_in = 21 -> 64, with scale_RGB fused into the LDS
 // load stage (networks.py:6-16 + slim conv2d_same root).  wt1 is [7][64][kConv1Ld] float32:
-// per kernel row kh, per output channel, the 7*21 (kw, c) taps in memory order of the
-// input row (+ zero padding), BN scale folded, channel-group reversal folded.
+// per kernel row kh, per output channel, a zero tap and then the 7*21 (kw, c) taps in memory order
+// of the input row (tap k at index k + 1: the kernels stage the input row from one element before the
+// window, which is a 16-byte boundary of the row), BN scale folded, channel-group reversal folded.
 constexpr int kConv1Cin = 21;
 constexpr int kConv1K = 7 * kConv1Cin;   // 147 taps per kernel row
-constexpr int kConv1Kpad = 148;          // rounded to the 4-k MFMA step
+constexpr int kConv1Kpad = 148;          // zero tap + 147, a whole number of 4-k MFMA steps
 constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conflict-free ds_read_b64)
-// wt1h (float16 precision only): the same taps as [7][64][kConv1LdH] float16, tap k at k + 1 behind a zero tap (the kernels
-// stage the input row from one element before the window: 16-byte aligned), rows zero-padded to 160.
+// wt1h (float16 precision only): the same row as [7][64][kConv1LdH] float16, zero-padded to 160.
 constexpr int kConv1LdH = 168;
 // wt1s ("f32s" precision only): float16 pieces [7][2][64][kConv1LdH], same tap positions: hi = f16(w), lo = f16((w - hi) * 2^11).
 int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const void *wt1s, const float *bias,

@@ -37,13 +37,13 @@ __device__ unsigned long long g_c1_stamps[8 * 65536];
 #define C1_STAMP() __builtin_amdgcn_s_memtime()
 #endif
 
-template <int NW, typename TO>
+template <int NW, typename TO, bool ALIGNED>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
 void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, const float *__restrict__ bias,
                   TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
   constexpr int NT = 64 * NW;
   constexpr int MI = 4 / (NW / 2);                       // 32-pixel MFMA blocks per wave: 2 or 1
-  constexpr int INLOADS = (C1_SEG_PAD + NT - 1) / NT;    // 22 or 11 dwords per thread per kernel row
+  constexpr int IN4 = (C1_SEG_PAD / 4 + NT - 1) / NT;    // 6 or 3 groups of four elements per thread per kernel row
   constexpr int WLOADS = (C1_WELEMS / 4 + NT - 1) / NT;  // 10 or 5 float4
   static_assert(C1_TILE * C1_LDC <= C1_WELEMS, "epilogue tile must fit in the weight stage");
   __shared__ __attribute__((aligned(16))) float w_s[C1_WELEMS];
@@ -62,29 +62,38 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  // element e of the staged segment is input-row float (2 wo0 - 3) * 21 + e.  Loads are issued
-  // UNCONDITIONALLY from a clamped index (a predicated load whose value feeds arithmetic makes
-  // hipcc wait for each load in turn: serialised L2 round trips); validity is a per-thread
-  // bit mask applied when the value is written to LDS.
-  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin;
+  // element e of the staged segment is input-row float (2 wo0 - 3) * 21 - 1 + e: the segment starts one element
+  // before the first window (the weight rows carry a zero tap in front), on a multiple of four elements of the
+  // row, and is fetched as 16-byte groups -- 6 loads and 6 LDS writes per thread and kernel row where
+  // element-wise staging issued 22 of each.  When the rows themselves are 16-byte aligned (ALIGNED: W a
+  // multiple of 4) every group is inside the row or outside it as a whole.  Loads are issued UNCONDITIONALLY
+  // from a clamped index (a predicated load whose value feeds arithmetic makes hipcc wait for each load in
+  // turn: serialised L2 round trips); validity is a per-thread bit mask applied when the value is written to LDS.
+  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
+  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[INLOADS];
-  int idx_i[INLOADS];
-  unsigned col_ok = 0;
+  float mean_i[4 * IN4];
+  long idx_i[IN4];
+  unsigned col_ok = 0, full = 0;
 #pragma unroll
-  for (int i = 0; i < INLOADS; ++i) {
-    const int e = tid + NT * i;
-    const long ge = seg0 + e;
-    // raw channel c of group g = c / 7 lands in output group 2 - g and gets that group's mean
-    const int c = e % kConv1Cin;
-    const int g = c / (kConv1Cin / 3);
-    mean_i[i] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
-    const bool ok = e < C1_SEG && ge >= 0 && ge < row_elems;
-    if (ok) col_ok |= 1u << i;
-    idx_i[i] = ok ? (int)ge : 0;
+  for (int i = 0; i < IN4; ++i) {
+    const int e0 = 4 * (tid + NT * i);
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      const long ge = seg0 + e;
+      // element e is raw channel c = (e - 1) mod 21 of its pixel; group g = c / 7 lands in output group 2 - g and gets that group's mean
+      const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);
+      mean_i[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+      if (e < C1_SEG_PAD && ge >= 0 && ge < row_elems) m |= 1u << j;
+    }
+    col_ok |= m << (4 * i);
+    if (m == 15u) full |= 1u << i;
+    idx_i[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;
   }
 
-  float in_reg[INLOADS];
+  floatx4 in_reg[IN4];
   floatx4 w_reg[WLOADS];
   bool row_ok = false;  // validity of the input row whose values sit in in_reg
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
@@ -93,7 +102,16 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = x + ((long)b * H + hc) * row_elems;
 #pragma unroll
-    for (int i = 0; i < INLOADS; ++i) in_reg[i] = xrow[idx_i[i]];
+    for (int i = 0; i < IN4; ++i) {
+      if constexpr (ALIGNED) {
+        in_reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx_i[i]);   // a group outside the row reads the row's first
+      } else if ((full >> i) & 1u) {
+        in_reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx_i[i]);
+      } else {   // a group that straddles the row's ends: element by element
+#pragma unroll
+        for (int j = 0; j < 4; ++j) in_reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx_i[i] + j] : 0.f;
+      }
+    }
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1 + (size_t)kh * C1_WELEMS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -104,12 +122,14 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
   auto store_stage = [&]() __attribute__((always_inline)) {
     const unsigned ok = row_ok ? col_ok : 0u;
 #pragma unroll
-    for (int i = 0; i < INLOADS; ++i) {
-      const int e = tid + NT * i;
+    for (int i = 0; i < IN4; ++i) {
+      const int q = tid + NT * i;
       // zero padding lives in the SCALED domain; x*255 and the subtraction round separately,
       // as the two TF ops do (this file is compiled with -ffp-contract=off)
-      const float v = in_reg[i] * 255.0f - mean_i[i];
-      if (e < C1_SEG_PAD) in_s[e] = ((ok >> i) & 1u) ? v : 0.f;
+      floatx4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? in_reg[i][j] * 255.0f - mean_i[4 * i + j] : 0.f;
+      if (q < C1_SEG_PAD / 4) reinterpret_cast<floatx4 *>(in_s)[q] = v;
     }
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -676,28 +696,33 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1
   ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
                  4.0 * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
   const dim3 grid((unsigned)blocks);
+  // rows that start on 16-byte boundaries: the kernels' staged segment then consists of whole aligned groups
+  const bool aligned = W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
   if (out_prec == kF32S && wt1s && g_conv1_variant != 2) {
-    if (W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+    if (aligned)
       hipLaunchKernelGGL((conv1_split_kernel<float, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
                          bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
     else
       hipLaunchKernelGGL((conv1_split_kernel<float, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
                          bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
   } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
-    if (W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+    if (aligned)
       hipLaunchKernelGGL((conv1_f16_kernel<_Float16, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
                          bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
     else
       hipLaunchKernelGGL((conv1_f16_kernel<_Float16, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
                          bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
   } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output
-    hipLaunchKernelGGL((conv1_kernel<4, _Float16>), grid, dim3(256), 0, s, x, wt1, bias,
+    hipLaunchKernelGGL((conv1_kernel<4, _Float16, false>), grid, dim3(256), 0, s, x, wt1, bias,
                        static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
-  } else if (g_conv1_variant == 0) {
-    hipLaunchKernelGGL((conv1_kernel<4, float>), grid, dim3(256), 0, s, x, wt1, bias, static_cast<float *>(y), H,
+  } else if (g_conv1_variant != 0) {
+    hipLaunchKernelGGL((conv1_kernel<8, float, false>), grid, dim3(512), 0, s, x, wt1, bias, static_cast<float *>(y), H,
+                       W, Ho, Wo, wtiles);
+  } else if (aligned) {
+    hipLaunchKernelGGL((conv1_kernel<4, float, true>), grid, dim3(256), 0, s, x, wt1, bias, static_cast<float *>(y), H,
                        W, Ho, Wo, wtiles);
   } else {
-    hipLaunchKernelGGL((conv1_kernel<8, float>), grid, dim3(512), 0, s, x, wt1, bias, static_cast<float *>(y), H,
+    hipLaunchKernelGGL((conv1_kernel<4, float, false>), grid, dim3(256), 0, s, x, wt1, bias, static_cast<float *>(y), H,
                        W, Ho, Wo, wtiles);
   }
   return check_launch("conv1_kernel");

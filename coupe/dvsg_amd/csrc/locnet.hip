@@ -165,8 +165,8 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
   return upload(net, shift, &L->bias);
 }
 
-// conv1: [7][64][kConv1Ld]; within a kernel row the taps run (kw, raw channel c) in input
-// memory order.  scale_RGB's group reversal (networks.py:10-14) is folded here: raw channel
+// conv1: [7][64][kConv1Ld]; within a kernel row a zero tap, then the taps (kw, raw channel c) in input
+// memory order (cnn_kernels.h).  scale_RGB's group reversal (networks.py:10-14) is folded here: raw channel
 // c multiplies the weight of scaled-tensor channel (2 - c/G) * G + c % G.
 int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, ConvLayer *L) {
   const HostArray *w;
@@ -180,21 +180,21 @@ int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Co
       for (int c = 0; c < cin; ++c) {
         const int cs = (2 - c / G) * G + c % G;
         for (int n = 0; n < 64; ++n)
-          wt[((size_t)kh * 64 + n) * kConv1Ld + kw * cin + c] =
+          wt[((size_t)kh * 64 + n) * kConv1Ld + 1 + kw * cin + c] =
               w->data[(((size_t)kh * 7 + kw) * cin + cs) * 64 + n] * scale[n];
       }
   std::vector<_Float16> wth((size_t)7 * 64 * kConv1LdH, (_Float16)0.f);
   for (int kh = 0; kh < 7; ++kh)
     for (int n = 0; n < 64; ++n)
       for (int k = 0; k < kConv1K; ++k)
-        wth[((size_t)kh * 64 + n) * kConv1LdH + k + 1] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k];   // behind a zero tap, like wts
+        wth[((size_t)kh * 64 + n) * kConv1LdH + k + 1] = (_Float16)wt[((size_t)kh * 64 + n) * kConv1Ld + k + 1];
   // "f32s" pieces, [7][2][64][kConv1LdH]: hi image then lo image per kernel row, lo scaled by 2^11; tap k sits at
   // k + 1 behind a zero tap (conv1_split_kernel stages the input row from one element before the window)
   std::vector<_Float16> wts((size_t)7 * 2 * 64 * kConv1LdH, (_Float16)0.f);
   for (int kh = 0; kh < 7; ++kh)
     for (int n = 0; n < 64; ++n)
       for (int k = 0; k < kConv1K; ++k) {
-        const float w32 = wt[((size_t)kh * 64 + n) * kConv1Ld + k];
+        const float w32 = wt[((size_t)kh * 64 + n) * kConv1Ld + k + 1];
         const _Float16 hi = (_Float16)w32;
         wts[(((size_t)kh * 2 + 0) * 64 + n) * kConv1LdH + k + 1] = hi;
         wts[(((size_t)kh * 2 + 1) * 64 + n) * kConv1LdH + k + 1] = (_Float16)((w32 - (float)hi) * 2048.0f);
