@@ -236,6 +236,25 @@ def test_ragged_and_extreme_shapes(net, synthetic_weights, B, H, W):
     assert np.abs(F16 - F_ref).max() < 3e-3
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("f32s", 1e-5), ("f16", 5e-5)])
+def test_window_tensor_off_the_16_byte_grid(net, synthetic_weights, precision, tol):
+    """conv1 stages its input rows as aligned 16-byte groups when it can; a window tensor that starts 4 bytes off
+    (a view into a larger buffer) takes the element-wise path and must give the same answer."""
+    import torch
+    B, H, W = 2, 40, 64
+    x = inputs.window_frames(251, B, H, W)
+    F_ref = onet.localizationNet(x, 25, synthetic_weights)
+    flat = torch.zeros(x.size + 8, dtype=torch.float32, device="cuda")
+    outs = []
+    for off in (0, 1, 3):
+        view = flat[off:off + x.size].view(B, H, W, x.shape[3])
+        view.copy_(torch.from_numpy(x))
+        assert view.data_ptr() % 16 == (4 * off) % 16
+        outs.append(net.forward(view, precision=precision).cpu().numpy())
+        assert np.abs(outs[-1] - F_ref).max() <= tol, (precision, off)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])   # same products, same order
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 200, 320), (2, 288, 512), (5, 150, 270), (7, 96, 416), (4, 360, 640)])
 def test_tile_count_regimes(net, synthetic_weights, B, H, W):
     """Shapes whose conv launches fall into the different work decompositions (split-K for a

@@ -25,7 +25,7 @@ def net(synthetic_weights):
     return LocNet(synthetic_weights)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100)])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100), (3, 33, 47)])   # 47: rows that are not 16-byte aligned
 def test_f16_stages_track_the_f32_oracle(net, synthetic_weights, B, H, W):
     x = inputs.window_frames(301, B, H, W)
     taps = {}
