@@ -27,10 +27,82 @@ namespace {
 // NW waves per workgroup: NW/2 along the pixels x 2 along the channels.
 // ----------------------------------------------------------------------------------------
 constexpr int C1_TILE = 128;
-constexpr int C1_SEG = (2 * (C1_TILE - 1) + 7) * kConv1Cin;  // 5481
-constexpr int C1_SEG_PAD = 5488;
+constexpr int C1_SEG_PAD = 5488;                              // staged elements: 1 + (2 * 127 + 7) * 21 = 5482, in whole groups of four
 constexpr int C1_WELEMS = 64 * kConv1Ld;                      // 9600 floats per kernel row
 constexpr int C1_LDC = 68;                                    // epilogue tile row stride
+
+// ----------------------------------------------------------------------------------------
+// The staged segment of an input row, shared by the three conv1 kernels.  Element e of the segment is
+// input-row float (2 wo0 - 3) * 21 - 1 + e: it starts one element before the first window (the weight rows
+// carry a zero tap in front), which is a multiple of four elements of the row, and is fetched as GROUPS
+// 16-byte groups per thread (thread tid: groups tid, tid + NT, ...) -- 6 loads per thread and kernel row
+// where element-wise fetching issued 22.  When the rows themselves are 16-byte aligned (ALIGNED: W a
+// multiple of 4) every group is inside the row or outside it as a whole and the loads are unconditional and
+// aligned; otherwise a group inside the row is one 4-byte-aligned dwordx4 load and a group that straddles
+// an end of the row goes element by element.  Loads are issued from clamped indices whatever the validity
+// (a predicated load whose value feeds arithmetic makes hipcc wait for each load in turn: serialised L2
+// round trips); validity is a per-thread bit mask applied when the value is scaled.
+// scale_RGB happens here, in float32: x * 255 - mean, two roundings like the TF ops (this file is compiled
+// with -ffp-contract=off); element e is raw channel (e - 1) mod 21 of its pixel, group g = c / 7 lands in
+// output group 2 - g and gets that group's mean; elements outside the image are 0 in the SCALED domain.
+// ----------------------------------------------------------------------------------------
+template <int NT, int GROUPS, bool ALIGNED>
+struct Conv1Row {
+  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
+  float mean[4 * GROUPS];
+  long idx[GROUPS];
+  unsigned col_ok, full;
+  floatx4 reg[GROUPS];   // the row in flight (prefetched under the previous kernel row's MFMAs)
+  bool row_ok;
+
+  __device__ __forceinline__ void init(int tid, int wo0, long row_elems, int seg_elems) {
+    const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
+    col_ok = full = 0;
+    row_ok = false;
+#pragma unroll
+    for (int i = 0; i < GROUPS; ++i) {
+      const int e0 = 4 * (tid + NT * i);
+      unsigned m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j;
+        const long ge = seg0 + e;
+        const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);
+        mean[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+        if (e < seg_elems && ge >= 0 && ge < row_elems) m |= 1u << j;
+      }
+      col_ok |= m << (4 * i);
+      if (m == 15u) full |= 1u << i;
+      idx[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;   // ALIGNED: a group outside the row reads the row's first
+    }
+  }
+  // input row 2 ho + kh - 3 of image b (clamped into the image; `row_ok` remembers whether it was inside)
+  __device__ __forceinline__ void load(const float *x, int b, int H, long row_elems, int ho, int kh) {
+    const int hi = 2 * ho + kh - 3;
+    row_ok = hi >= 0 && hi < H;
+    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+    const float *xrow = x + ((long)b * H + hc) * row_elems;
+#pragma unroll
+    for (int i = 0; i < GROUPS; ++i) {
+      if constexpr (ALIGNED) {
+        reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx[i]);
+      } else if ((full >> i) & 1u) {
+        reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx[i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx[i] + j] : 0.f;
+      }
+    }
+  }
+  // group i of the row in flight, scaled
+  __device__ __forceinline__ floatx4 scaled(int i) const {
+    const unsigned ok = row_ok ? col_ok : 0u;
+    floatx4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? reg[i][j] * 255.0f - mean[4 * i + j] : 0.f;
+    return v;
+  }
+};
 
 #ifdef DVSG_STAMPS  // diagnostic build (tools/stamp_probe_conv1.py): per-workgroup phase times of conv1_kernel
 __device__ unsigned long long g_c1_stamps[8 * 65536];
@@ -62,56 +134,12 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  // element e of the staged segment is input-row float (2 wo0 - 3) * 21 - 1 + e: the segment starts one element
-  // before the first window (the weight rows carry a zero tap in front), on a multiple of four elements of the
-  // row, and is fetched as 16-byte groups -- 6 loads and 6 LDS writes per thread and kernel row where
-  // element-wise staging issued 22 of each.  When the rows themselves are 16-byte aligned (ALIGNED: W a
-  // multiple of 4) every group is inside the row or outside it as a whole.  Loads are issued UNCONDITIONALLY
-  // from a clamped index (a predicated load whose value feeds arithmetic makes hipcc wait for each load in
-  // turn: serialised L2 round trips); validity is a per-thread bit mask applied when the value is written to LDS.
-  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
-  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[4 * IN4];
-  long idx_i[IN4];
-  unsigned col_ok = 0, full = 0;
-#pragma unroll
-  for (int i = 0; i < IN4; ++i) {
-    const int e0 = 4 * (tid + NT * i);
-    unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = e0 + j;
-      const long ge = seg0 + e;
-      // element e is raw channel c = (e - 1) mod 21 of its pixel; group g = c / 7 lands in output group 2 - g and gets that group's mean
-      const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);
-      mean_i[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
-      if (e < C1_SEG_PAD && ge >= 0 && ge < row_elems) m |= 1u << j;
-    }
-    col_ok |= m << (4 * i);
-    if (m == 15u) full |= 1u << i;
-    idx_i[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;
-  }
-
-  floatx4 in_reg[IN4];
+  Conv1Row<NT, IN4, ALIGNED> row;
+  row.init(tid, wo0, row_elems, C1_SEG_PAD);
   floatx4 w_reg[WLOADS];
-  bool row_ok = false;  // validity of the input row whose values sit in in_reg
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
-    const int hi = 2 * ho + kh - 3;
-    row_ok = hi >= 0 && hi < H;
-    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
-    const float *xrow = x + ((long)b * H + hc) * row_elems;
-#pragma unroll
-    for (int i = 0; i < IN4; ++i) {
-      if constexpr (ALIGNED) {
-        in_reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx_i[i]);   // a group outside the row reads the row's first
-      } else if ((full >> i) & 1u) {
-        in_reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx_i[i]);
-      } else {   // a group that straddles the row's ends: element by element
-#pragma unroll
-        for (int j = 0; j < 4; ++j) in_reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx_i[i] + j] : 0.f;
-      }
-    }
+    row.load(x, b, H, row_elems, ho, kh);
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1 + (size_t)kh * C1_WELEMS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -120,15 +148,10 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     }
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
-    const unsigned ok = row_ok ? col_ok : 0u;
 #pragma unroll
     for (int i = 0; i < IN4; ++i) {
       const int q = tid + NT * i;
-      // zero padding lives in the SCALED domain; x*255 and the subtraction round separately,
-      // as the two TF ops do (this file is compiled with -ffp-contract=off)
-      floatx4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? in_reg[i][j] * 255.0f - mean_i[4 * i + j] : 0.f;
+      const floatx4 v = row.scaled(i);
       if (q < C1_SEG_PAD / 4) reinterpret_cast<floatx4 *>(in_s)[q] = v;
     }
 #pragma unroll
@@ -319,68 +342,30 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  // the row segment starts one element before the first window (zero tap in front of the weights) and is fetched as
-  // 16-byte groups: see conv1_split_kernel
-  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
-  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[4 * C1H_IN4];
-  long idx_i[C1H_IN4];
-  unsigned col_ok = 0, full = 0;
-#pragma unroll
-  for (int i = 0; i < C1H_IN4; ++i) {
-    const int e0 = 4 * (tid + 256 * i);
-    unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = e0 + j;
-      const long ge = seg0 + e;
-      const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);
-      mean_i[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
-      if (e < C1H_SEG && ge >= 0 && ge < row_elems) m |= 1u << j;
-    }
-    col_ok |= m << (4 * i);
-    if (m == 15u) full |= 1u << i;
-    idx_i[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;
-  }
+  Conv1Row<256, C1H_IN4, ALIGNED> row;
+  row.init(tid, wo0, row_elems, C1H_SEG);
 
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
-  floatx4 in_reg[C1H_IN4];
-  bool row_ok = false;
   auto load_stage = [&](int kh, int buf) __attribute__((always_inline)) {
     // weights of kernel row kh: 21 pieces of 1 KiB, piece j by wave j % 4, straight into LDS
     const char *wsrc = reinterpret_cast<const char *>(wt1h) + (size_t)kh * C1H_WBYTES;
     for (int j = wave; j < C1H_WBYTES / 1024; j += 4)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024 + lane * 16), (lptr_t)(w_s + buf * C1H_WBYTES + j * 1024),
                                        16, 0, 0);
-    const int hi = 2 * ho + kh - 3;
-    row_ok = hi >= 0 && hi < H;
-    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
-    const float *xrow = x + ((long)b * H + hc) * row_elems;
-#pragma unroll
-    for (int i = 0; i < C1H_IN4; ++i) {
-      if constexpr (ALIGNED) {
-        in_reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx_i[i]);
-      } else if ((full >> i) & 1u) {
-        in_reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx_i[i]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) in_reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx_i[i] + j] : 0.f;
-      }
-    }
+    row.load(x, b, H, row_elems, ho, kh);
   };
   auto store_stage = [&](int buf) __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    const unsigned ok = row_ok ? col_ok : 0u;
     half4_t *dst = reinterpret_cast<half4_t *>(in_s + buf * C1H_SEG * 2);
 #pragma unroll
     for (int i = 0; i < C1H_IN4; ++i) {
       const int q = tid + 256 * i;
+      const floatx4 v = row.scaled(i);   // then one rounding to f16
       half4_t hv;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)   // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops), then one rounding to f16
-        hv[j] = (_Float16)(((ok >> (4 * i + j)) & 1u) ? in_reg[i][j] * 255.0f - mean_i[4 * i + j] : 0.f);
+      for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
       if (q < C1H_SEG / 4) dst[q] = hv;
     }
   };
@@ -493,53 +478,12 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  // The row segment is fetched as 16-byte groups of four consecutive elements, 6 loads per thread and kernel
-  // row where element-wise fetching issued 22, and two 8-byte LDS writes per group and image.  The segment
-  // starts one element before the first window (the weights carry a zero tap in front), which puts it on a
-  // multiple of four elements of the row: when the rows themselves are 16-byte aligned (ALIGNED: W a multiple
-  // of 4) every group is inside the row or outside it as a whole and the loads are unconditional and aligned.
-  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
-  const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
   const long row_elems = (long)W * kConv1Cin;
-  float mean_i[4 * C1S_IN4];
-  long idx_i[C1S_IN4];
-  unsigned col_ok = 0, full = 0;
-#pragma unroll
-  for (int i = 0; i < C1S_IN4; ++i) {
-    const int e0 = 4 * (tid + NT * i);
-    unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = e0 + j;
-      const long ge = seg0 + e;
-      const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);   // element e is channel (e - 1) mod 21 of its pixel
-      mean_i[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
-      if (e < C1S_SEG && ge >= 0 && ge < row_elems) m |= 1u << j;
-    }
-    col_ok |= m << (4 * i);
-    if (m == 15u) full |= 1u << i;
-    idx_i[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;
-  }
-
-  floatx4 in_reg[C1S_IN4];
+  Conv1Row<NT, C1S_IN4, ALIGNED> row;
+  row.init(tid, wo0, row_elems, C1S_SEG);
   floatx4 w_reg[WLOADS];
-  bool row_ok = false;
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
-    const int hi = 2 * ho + kh - 3;
-    row_ok = hi >= 0 && hi < H;
-    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
-    const float *xrow = x + ((long)b * H + hc) * row_elems;
-#pragma unroll
-    for (int i = 0; i < C1S_IN4; ++i) {
-      if constexpr (ALIGNED) {
-        in_reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx_i[i]);   // a group outside the row reads the row's first
-      } else if ((full >> i) & 1u) {
-        in_reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx_i[i]);
-      } else {   // a group that straddles the row's ends: element by element
-#pragma unroll
-        for (int j = 0; j < 4; ++j) in_reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx_i[i] + j] : 0.f;
-      }
-    }
+    row.load(x, b, H, row_elems, ho, kh);
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1s + (size_t)kh * C1S_WHALFS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -549,17 +493,15 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    const unsigned ok = row_ok ? col_ok : 0u;
 #pragma unroll
     for (int i = 0; i < C1S_IN4; ++i) {
       const int q = tid + NT * i;
+      const floatx4 v = row.scaled(i);   // then the two pieces
       half4_t hv, lv;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        // scale_RGB in float32 (x * 255 - mean, two roundings like the TF ops: -ffp-contract=off), then the two pieces
-        const float v = ((ok >> (4 * i + j)) & 1u) ? in_reg[i][j] * 255.0f - mean_i[4 * i + j] : 0.f;
-        hv[j] = (_Float16)v;
-        lv[j] = (_Float16)(v - (float)hv[j]);
+        hv[j] = (_Float16)v[j];
+        lv[j] = (_Float16)(v[j] - (float)hv[j]);
       }
       if (q < C1S_SEG / 4) {
         reinterpret_cast<half4_t *>(in_hi)[q] = hv;
