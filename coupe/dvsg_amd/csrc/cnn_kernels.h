@@ -44,6 +44,9 @@ struct ConvGemm {
 constexpr int kSplitKMaxTiles = 512;                                   // tickets one launch may use
 constexpr size_t kSplitKSlabBytes = (size_t)512 * 2 * 128 * 128 * 4;   // 64 MiB: 512 workgroups x 2 partial 128x128 f32 tiles (stream-K tail)
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
+// Zeroes n split-K / stream-K tickets with a KERNEL: a hipMemsetAsync captured into a HIP graph (memset node) did not
+// take effect on the second and later replays of the graph on ROCm 7.2 (tests/test_gpu_cnn.py::test_a_step_replays_...).
+int launch_zero_tickets(int *tickets, size_t n, hipStream_t s);
 // conv2 (3x3, Cin -> 64, stride 1/2, pad 1, + bias + ReLU) followed by conv3 (1x1, 64 -> Cout, + bias +
 // residual + ReLU) of a bottleneck unit whose middle width is 64 (block 1), fused: the [M,64]
 // intermediate stays in LDS.  float32 only.

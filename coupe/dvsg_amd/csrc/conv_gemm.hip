@@ -640,6 +640,19 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
 
 void set_conv_variant(int v) { g_conv_variant = v; }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_tickets_kernel(int *__restrict__ t, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) t[i] = 0;
+}
+}  // namespace
+
+int launch_zero_tickets(int *tickets, size_t n, hipStream_t s) {
+  if (n == 0) return DVSG_OK;
+  hipLaunchKernelGGL(zero_tickets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tickets, n);
+  return check_launch("zero_tickets_kernel");
+}
+
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   DVSG_REQUIRE(p.prec == kF32 || p.prec == kF16, "conv_gemm: unknown precision %d", p.prec);
   DVSG_REQUIRE(p.ksize == 1 || p.ksize == 3, "conv_gemm: kernel size %d unsupported", p.ksize);

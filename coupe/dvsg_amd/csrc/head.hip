@@ -165,6 +165,7 @@ int launch_f16_to_f32(const void *x, float *y, size_t n, hipStream_t s) {
 
 int launch_p_to_f32(const void *x, float *y, size_t n, hipStream_t s) {
   DVSG_REQUIRE(n % 32 == 0, "p_to_f32: %zu elements are not whole 32-element groups", n);
+  if (n == 0) return DVSG_OK;
   const size_t want = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(p_to_f32_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, x, y, n / 4);
   return check_launch("p_to_f32_kernel");
@@ -172,6 +173,7 @@ int launch_p_to_f32(const void *x, float *y, size_t n, hipStream_t s) {
 
 int launch_f32_to_p(const float *x, void *y, size_t n, hipStream_t s) {
   DVSG_REQUIRE(n % 32 == 0, "f32_to_p: %zu elements are not whole 32-element groups", n);
+  if (n == 0) return DVSG_OK;
   const size_t want = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(f32_to_p_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, x, y, n / 4);
   return check_launch("f32_to_p_kernel");

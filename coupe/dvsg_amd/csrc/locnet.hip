@@ -339,7 +339,7 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
   } while (0)
 
   // split-K tickets of every conv launch of this pass (each launch owns its own segment)
-  DVSG_HIP(hipMemsetAsync(ws.splitk_counters, 0, (size_t)kMaxConvLaunches * kSplitKMaxTiles * sizeof(int), s));
+  DVSG_RUN(launch_zero_tickets(ws.splitk_counters, (size_t)kMaxConvLaunches * kSplitKMaxTiles, s));
   int launch_idx = 0;
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
   DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s, net->conv1.bias, ws.bufA, B, H,
@@ -451,7 +451,7 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
   p.relu = relu;
   const size_t cbytes = align256((size_t)kSplitKMaxTiles * sizeof(int));
   if (scratch && scratch_bytes > cbytes) {  // [tickets | partial-tile slabs]
-    DVSG_HIP(hipMemsetAsync(scratch, 0, cbytes, as_stream(stream)));
+    if (int rc = launch_zero_tickets(static_cast<int *>(scratch), cbytes / sizeof(int), as_stream(stream))) return rc;
     p.splitk_counters = static_cast<int *>(scratch);
     p.splitk_scratch = static_cast<char *>(scratch) + cbytes;
     p.splitk_scratch_bytes = scratch_bytes - cbytes;

@@ -236,6 +236,36 @@ def test_ragged_and_extreme_shapes(net, synthetic_weights, B, H, W):
     assert np.abs(F16 - F_ref).max() < 3e-3
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+def test_a_step_replays_from_a_captured_hip_graph(net, precision):
+    """The library allocates and synchronises nothing inside a call: a dvsg_stabilize_* step can be
+    captured into a HIP graph as it stands and replays bit for bit, split-K tickets included."""
+    import torch
+    B, H, W = 2, 96, 160
+    dev = torch.device("cuda")
+    x = torch.from_numpy(inputs.window_frames(261, B, H, W)).to(dev)
+    u = x[..., 18:].contiguous()
+    out = torch.empty((B, H, W, 3), device=dev)
+    F = torch.empty((B, 25, 2), device=dev)
+    net.stabilize(x, u, out, F, precision=precision)
+    torch.cuda.synchronize()
+    ref_out, ref_F = out.clone(), F.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        net.stabilize(x, u, out, F, precision=precision)   # workspace sized before the capture
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        net.stabilize(x, u, out, F, precision=precision)
+    for _ in range(3):
+        out.zero_()
+        F.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(F, ref_F), float((F - ref_F).abs().max())
+        assert torch.equal(out, ref_out), float((out - ref_out).abs().max())
+
+
 @pytest.mark.parametrize("precision,tol", [("f32", 1e-5), ("f32s", 1e-5), ("f16", 5e-5)])
 def test_window_tensor_off_the_16_byte_grid(net, synthetic_weights, precision, tol):
     """conv1 stages its input rows as aligned 16-byte groups when it can; a window tensor that starts 4 bytes off

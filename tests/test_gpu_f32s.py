@@ -81,6 +81,20 @@ def test_pieces_round_trip():
     assert float(err[0, 0, 0, :3].max()) == 0.0
 
 
+def test_pieces_conversions_reject_ragged_sizes_and_accept_none():
+    import torch
+    from coupe.dvsg_amd import _lib
+    t = torch.zeros(64, device="cuda")
+    out = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("dvsg_f32_to_pieces", t.data_ptr(), out.data_ptr(), 0, st)       # nothing to do: fine
+    _lib.call("dvsg_pieces_to_f32", out.data_ptr(), t.data_ptr(), 0, st)
+    with pytest.raises(_lib.DvsgError):
+        _lib.call("dvsg_f32_to_pieces", t.data_ptr(), out.data_ptr(), 40, st)  # not whole 32-element groups
+    with pytest.raises(_lib.DvsgError):
+        _lib.call("dvsg_pieces_to_f32", 0, t.data_ptr(), 64, st)
+
+
 def test_layers_against_float64(net):
     """dvsg_conv_gemm_f32s on single layers (3x3 / 1x1, stride 2, residual; small batch = split-K, large =
     plain tiles and the stream-K tail) against float64 math on the same operands (the inputs as the mode

@@ -32,7 +32,7 @@ def timed(fn, n=20):
     return (time.perf_counter() - t0) / n * 1e3
 
 plain = timed(step)
-ref = out.clone()
+ref, ref_F = out.clone(), F.clone()
 side = torch.cuda.Stream()
 with torch.cuda.stream(side):
     step()
@@ -42,4 +42,4 @@ with torch.cuda.graph(g, stream=side):
     step()
 graph = timed(g.replay)
 print("%s: plain %.3f ms/step, graph replay %.3f ms/step (%.2f %%), identical output: %s" %
-      (prec, plain, graph, 100 * (plain / graph - 1), bool(torch.equal(out, ref))))
+      (prec, plain, graph, 100 * (plain / graph - 1), bool(torch.equal(out, ref) and torch.equal(F, ref_F))))
