@@ -270,8 +270,12 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # DVSG_BENCH_FORCE_DIST=1: a one-rank process group anyway, so that the RCCL calls of the N > 1 path (async gather,
+    # device barrier) run on a one-GPU box
+    if world > 1 or os.environ.get("DVSG_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         # "nccl" is RCCL on ROCm; rendezvous comes from the launcher's MASTER_ADDR / MASTER_PORT
         dist.init_process_group(backend, rank=rank, world_size=world)
     on_host = backend != "nccl"

@@ -57,6 +57,16 @@ def test_bench_tf_warp_workload():
     assert d["roofline"]["kernel"] == "stn_kernel" and d["roofline"]["launches"] == 2 and d["cpu_baseline"]["cores"] == 1
 
 
+def test_bench_rccl_calls_of_the_sharded_path_run_on_one_rank():
+    """The N > 1 path's RCCL calls (async gather of the shard's output, device barrier, max-reduce of the time) on a
+    one-rank process group: what a one-GPU box can exercise of the backend the 8-GPU run uses."""
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4", "--call-batch", "2", "--height", "96",
+             "--width", "160", "--no-cpu-baseline", "--no-secondary", env={"DVSG_BENCH_FORCE_DIST": "1"})
+    c = d["config"]
+    assert c["backend"] == "rccl" and c["gather"] is True and c["ranks_seen"] == 1
+    assert c["windows_per_step"] == 4 and c["windows_per_call"] == 2 and d["value"] > 0
+
+
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no launcher around it (what the driver runs): the script spawns
     its two ranks itself, each stabilises its shard in calls of `windows_per_call`, the frames are
