@@ -1,0 +1,177 @@
+// Diagnostic: the "f32s" (float16 pieces) GEMM main loop in isolation -- LDS-DMA of the next stages from a buffer
+// far larger than the caches, fragment ds_read_b128, three v_mfma_f32_32x32x16_f16 per product block -- in the
+// product's configuration and in candidates with less LDS traffic per product:
+//   P0  128 x 128 tile, 4 waves of 64 x 64, 2 LDS stages, 2 workgroups per CU, hipcc's schedule of the reads (product)
+//   P1  P0 with the fragment reads software-pipelined across the stage barrier (k-step t+1 requested before the
+//       MFMAs of k-step t; the first k-step of the next stage right behind the barrier)
+//   P2  128 x 256 tile, 4 waves of 64 x 128 (a quarter fewer LDS bytes per product), 3 LDS stages (two of lead),
+//       1 workgroup per CU, pipelined like P1
+//   P3  256 x 128 tile, 4 waves of 128 x 64, otherwise P2
+//   P4  P2 with 2 LDS stages
+// Prints f32-equivalent TFLOP/s (2 M N K per product block, whatever the number of MFMAs behind it; roof 833).
+// Measured (MI355X, 72 stages, 16 workgroups per source window, windows within 24 MiB / 192 MiB / 3 GiB):
+//   P0 430 / 494 / 470    P1 437 / 486 / 456    P2 413 / 428 / 421    P3 438 / 433 / 422    P4 451 / 453 / 416
+// i.e. the product's configuration is as good as any of them and explicit pipelining of the reads buys nothing here
+// (two workgroups per CU already cover each other's LDS round trips): the loop itself runs at 52-59 % of the pieces
+// roof, and what a whole 3x3 layer loses against it (310 in the product) is outside the loop.
+//   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+constexpr int ROWB = 128;
+
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE>
+__global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const char *src, size_t src_bytes) {
+  constexpr int NW = WM * WN, MI = BM / WM / 32, NI = BN / WN / 32;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int PER = (BM + BN) / 8 / NW;   // LDS-DMA instructions per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+  const int sw = (r >> 1) & 7;
+  floatx16 acc[MI][NI];
+  for (int mi = 0; mi < MI; ++mi)
+    for (int ni = 0; ni < NI; ++ni)
+      for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+  // stage s, row group g of 8 rows = 1 KiB.  The product's operands mostly come out of L2 (weights; the taps and the
+  // n-tiles re-reading an activation tile), so 16 workgroups share a source window and the windows together (src_bytes)
+  // can be sized to sit in L2, in the Infinity Cache or in neither
+  const size_t wg_span = (size_t)stages * STAGE;
+  const char *my = src + ((size_t)(blockIdx.x / 16) * wg_span) % (src_bytes - wg_span);
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    char *dst = lds + (s % NS) * STAGE;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int g = wave + NW * i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(my + (size_t)s * STAGE + g * 1024 + lane * 16), (lptr_t)(dst + g * 1024), 16, 0, 0);
+    }
+  };
+  struct Frags {
+    halfx8 ahi[MI], alo[MI], bhi[NI], blo[NI];
+  };
+  auto read = [&](Frags &f, int s, int t) __attribute__((always_inline)) {
+    const char *a = lds + (s % NS) * STAGE + (wm * (BM / WM) + r) * ROWB;
+    const char *b = lds + (s % NS) * STAGE + BM * ROWB + (wn * (BN / WN) + r) * ROWB;
+    const int g = 2 * t + h;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      f.ahi[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * (g ^ sw));
+      f.alo[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * ((4 + g) ^ sw));
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      f.bhi[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * (g ^ sw));
+      f.blo[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * ((4 + g) ^ sw));
+    }
+  };
+  auto mma = [&](const Frags &f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[mi], f.bhi[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.alo[mi], f.bhi[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[mi], f.blo[ni], acc[mi][ni], 0, 0, 0);
+      }
+  };
+  if constexpr (!PIPE) {
+    // the product's order: barrier, DMA of the stage NS - 1 ahead, then the stage's reads and MFMAs
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    for (int s = 0; s < stages; ++s) {
+      // stage s has landed once at most the NS - 2 younger stages are outstanding
+      if (NS == 2 || s + NS - 2 >= stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + NS - 1 < stages) issue(s + NS - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      Frags f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        read(f, s, t);
+        mma(f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  } else {
+    // all NS buffers in flight; the barrier sits in the MIDDLE of a stage, behind the request of its last fragments:
+    // past it every read of stage s has returned (its buffer takes stage s + NS) and stage s + 1 is visible, whose
+    // first fragments are requested before the second half of stage s's MFMAs is issued
+#pragma unroll
+    for (int s = 0; s < NS; ++s) issue(s);
+    Frags f0, f1;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read(f0, 0, 0);
+    for (int s = 0; s < stages; ++s) {
+      read(f1, s, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (NS == 2 || s + NS > stages) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PER) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + NS < stages) issue(s + NS);
+      if (s + 1 < stages) read(f0, s + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float sum = 0.f;
+  for (int mi = 0; mi < MI; ++mi)
+    for (int ni = 0; ni < NI; ++ni)
+      for (int q = 0; q < 16; ++q) sum += acc[mi][ni][q];
+  if (sum == 12345.678f) out[tid] = sum;  // keep the accumulators live
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE>
+void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, float *out) {
+  const int stages = 72, grid = 256 * wgs_per_cu * 6;
+  const size_t lds = (size_t)NS * (BM + BN) * ROWB;
+  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 12; ++rep) {   // back to back: the clock governor settles
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, out, stages, src, src_bytes);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep >= 4 && ms < best) best = ms;
+  }
+  const double flops = 2.0 * BM * BN * 32.0 * stages * grid;
+  std::printf("%-64s %8.3f ms  %7.1f f32-equivalent TFLOP/s  (%s)\n", name, best, flops / best / 1e9,
+              hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+  const size_t alloc = (size_t)3 << 30;
+  char *src;
+  float *out;
+  if (hipMalloc(&src, alloc) != hipSuccess || hipMalloc(&out, 4096) != hipSuccess) return 1;
+  (void)hipMemset(src, 0x3c, alloc);   // finite float16 values (0x3c3c = 1.06)
+  for (size_t src_bytes : {(size_t)24 << 20, (size_t)192 << 20, alloc}) {
+  std::printf("== source windows within %zu MiB\n", src_bytes >> 20);
+  run<128, 128, 2, 2, 2, false>("P0 128x128, 4 x (64x64), 2 stages, 2 WG/CU (product)", 2, src, src_bytes, out);
+  run<128, 128, 2, 2, 2, true>("P1 P0 + reads pipelined across the barrier", 2, src, src_bytes, out);
+  run<128, 256, 2, 2, 3, true>("P2 128x256, 4 x (64x128), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  run<256, 128, 2, 2, 3, true>("P3 256x128, 4 x (128x64), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  run<128, 256, 2, 2, 2, true>("P4 128x256, 4 x (64x128), 2 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  }
+  return 0;
+}

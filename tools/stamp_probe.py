@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup phase times of conv_gemm_kernel (mode 0) from a -DDVSG_STAMPS build of the library:
-   DVSG_AMD_LIB=build/lib_stamps.so python tools/stamp_probe.py B,H,W,Cin,Cout,k [...]"""
+   DVSG_AMD_LIB=build/lib_stamps.so python tools/stamp_probe.py B,H,W,Cin,Cout,k [...]
+   (PROBE_PREC=f32s: the pieces kernels; PROBE_RES=1: with a residual, a unit's conv3; PROBE_REP=20: warmed-up clock)"""
 import os, sys
 import numpy as np
 import torch
@@ -18,6 +19,8 @@ for arg in sys.argv[1:]:
     wt = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
     bias = torch.rand((cout,), generator=g, device=dev) - 0.5
     y = torch.empty((B, H, W, cout), device=dev)
+    res = torch.rand((B, H, W, cout), generator=g, device=dev) if os.environ.get("PROBE_RES") == "1" else None   # a unit's conv3
+    RES = res.data_ptr() if res is not None else 0
     FN = "dvsg_conv_gemm_f32"
     if os.environ.get("PROBE_PREC") == "f32s":   # float16 pieces [Cout][K/32][32 hi | 32 lo]
         FN = "dvsg_conv_gemm_f32s"
@@ -29,11 +32,11 @@ for arg in sys.argv[1:]:
     REP = int(os.environ.get("PROBE_REP", "1"))     # back-to-back launches before the measured one (clock governor settles)
     for rnd in range(3):
         for _ in range(REP - 1):
-            _lib.call(FN, x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y.data_ptr(), B, H, W, cin, cout, k,
+            _lib.call(FN, x.data_ptr(), wt.data_ptr(), bias.data_ptr(), RES, y.data_ptr(), B, H, W, cin, cout, k,
                       1, 1, 1, scratch.data_ptr(), scratch.numel(), stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.call(FN, x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y.data_ptr(), B, H, W, cin, cout, k,
+        _lib.call(FN, x.data_ptr(), wt.data_ptr(), bias.data_ptr(), RES, y.data_ptr(), B, H, W, cin, cout, k,
                   1, 1, 1, scratch.data_ptr(), scratch.numel(), stream)
         e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3
