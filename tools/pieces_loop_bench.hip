@@ -13,7 +13,8 @@
 //   P0 430 / 494 / 470    P1 437 / 486 / 456    P2 413 / 428 / 421    P3 438 / 433 / 422    P4 451 / 453 / 416
 // i.e. the product's configuration is as good as any of them and explicit pipelining of the reads buys nothing here
 // (two workgroups per CU already cover each other's LDS round trips): the loop itself runs at 52-59 % of the pieces
-// roof, and what a whole 3x3 layer loses against it (310 in the product) is outside the loop.
+// roof, 1.25 us per stage like the product's workgroups; a whole 3x3 layer (310 in the product) then loses its
+// partly filled last round of tiles and the tile prologues / epilogues.
 //   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
 #include <hip/hip_runtime.h>
 
