@@ -40,6 +40,13 @@
 // flight before the current tile's last one, with the transpose squeezed into the one free stage
 // buffer in two 64-row rounds, gained 7 % on the K = 64 layers and lost 2-5 % everywhere else.)
 //
+// (float16 mode, round 2: its loop is bound by the L2 -> LDS stream -- tools/pieces_loop_bench.hip: every 128 x 128
+// configuration, 4 or 8 waves, fragment reads pipelined or not, runs at the same ~15 TB/s of LDS-DMA -- and a 128 x 256
+// tile of two [hi | lo] channel groups with a ring of three LDS stages, one workgroup per CU, is 20 % faster in that
+// loop.  Built into this kernel (BN = 256, plain tiles) it LOST 4.5 % end to end at 720p and 6 % at 4K (3x3 class 2.72
+// vs 2.54 ms): with a single workgroup per CU nobody multiplies while a tile's prologue, first-stage wait and 133 KB
+// transpose run.  Removed again.)
+//
 // Where the main loop's time goes (ablations at batch 16, 720p, plain tiles): with the LDS-DMA
 // removed the 52 launches of a step take 17.8 ms instead of 19.6, and exactly the same with the DMA
 // left in but the activation addresses folded into a 256 KB (L2-resident) window; removing the

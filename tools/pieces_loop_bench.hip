@@ -15,6 +15,9 @@
 // (two workgroups per CU already cover each other's LDS round trips): the loop itself runs at 52-59 % of the pieces
 // roof, 1.25 us per stage like the product's workgroups; a whole 3x3 layer (310 in the product) then loses its
 // partly filled last round of tiles and the tile prologues / epilogues.
+// float16 mode loop (H*): 128 x 128 tiles 495-505 whatever the wave layout (the L2 -> LDS stream, ~15 TB/s, bounds it);
+// 128 x 256 tiles, 3 stages, 1 workgroup per CU 570-610 -- but built into conv_gemm_kernel that configuration lost
+// 4.5-6 % end to end (nobody multiplies during a tile's prologue / epilogue with one workgroup per CU).
 //   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
 #include <hip/hip_runtime.h>
 
@@ -27,8 +30,8 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 
 constexpr int ROWB = 128;
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE>
-__global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const char *src, size_t src_bytes) {
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false>
+__global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stages, const char *src, size_t src_bytes) {
   constexpr int NW = WM * WN, MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int PER = (BM + BN) / 8 / NW;   // LDS-DMA instructions per wave and stage
@@ -53,8 +56,12 @@ __global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const
       __builtin_amdgcn_global_load_lds((gptr_t)(my + (size_t)s * STAGE + g * 1024 + lane * 16), (lptr_t)(dst + g * 1024), 16, 0, 0);
     }
   };
+  // F16 (the float16 mode: f16 activations, [hi | lo] weight rows stacked along N): four 16-k steps per 128-byte
+  // stage, one fragment per operand block and one MFMA per block pair; else the pieces loop (two steps, hi / lo
+  // fragments, three MFMAs per block pair)
+  constexpr int TSTEPS = F16 ? 4 : 2;
   struct Frags {
-    halfx8 ahi[MI], alo[MI], bhi[NI], blo[NI];
+    halfx8 ahi[MI], alo[F16 ? 1 : MI], bhi[NI], blo[F16 ? 1 : NI];
   };
   auto read = [&](Frags &f, int s, int t) __attribute__((always_inline)) {
     const char *a = lds + (s % NS) * STAGE + (wm * (BM / WM) + r) * ROWB;
@@ -63,12 +70,12 @@ __global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       f.ahi[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * (g ^ sw));
-      f.alo[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * ((4 + g) ^ sw));
+      if constexpr (!F16) f.alo[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * ((4 + g) ^ sw));
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       f.bhi[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * (g ^ sw));
-      f.blo[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * ((4 + g) ^ sw));
+      if constexpr (!F16) f.blo[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * ((4 + g) ^ sw));
     }
   };
   auto mma = [&](const Frags &f) __attribute__((always_inline)) {
@@ -77,8 +84,10 @@ __global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[mi], f.bhi[ni], acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.alo[mi], f.bhi[ni], acc[mi][ni], 0, 0, 0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[mi], f.blo[ni], acc[mi][ni], 0, 0, 0);
+        if constexpr (!F16) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.alo[mi], f.bhi[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[mi], f.blo[ni], acc[mi][ni], 0, 0, 0);
+        }
       }
   };
   if constexpr (!PIPE) {
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const
       __builtin_amdgcn_sched_barrier(0);
       Frags f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < TSTEPS; ++t) {
         read(f, s, t);
         mma(f);
       }
@@ -108,24 +117,27 @@ __global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const
     // first fragments are requested before the second half of stage s's MFMAs is issued
 #pragma unroll
     for (int s = 0; s < NS; ++s) issue(s);
-    Frags f0, f1;
+    Frags fr[2];
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PER) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    read(f0, 0, 0);
+    read(fr[0], 0, 0);
     for (int s = 0; s < stages; ++s) {
-      read(f1, s, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f0);
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TSTEPS - 1; ++t) {
+        read(fr[(t + 1) & 1], s, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fr[t & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (NS == 2 || s + NS > stages) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PER) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (s + NS < stages) issue(s + NS);
-      if (s + 1 < stages) read(f0, s + 1, 0);
+      if (s + 1 < stages) read(fr[0], s + 1, 0);   // TSTEPS is even: the last step of a stage sits in fr[1]
       __builtin_amdgcn_sched_barrier(0);
-      mma(f1);
+      mma(fr[1]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -136,11 +148,11 @@ __global__ __launch_bounds__(256) void loop_kernel(float *out, int stages, const
   if (sum == 12345.678f) out[tid] = sum;  // keep the accumulators live
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false>
 void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, float *out) {
   const int stages = 72, grid = 256 * wgs_per_cu * 6;
   const size_t lds = (size_t)NS * (BM + BN) * ROWB;
-  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE>;
+  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -148,14 +160,15 @@ void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, fl
   float best = 1e30f;
   for (int rep = 0; rep < 12; ++rep) {   // back to back: the clock governor settles
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, 0, out, stages, src, src_bytes);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, 0, out, stages, src, src_bytes);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep >= 4 && ms < best) best = ms;
   }
-  const double flops = 2.0 * BM * BN * 32.0 * stages * grid;
+  // F16: a 128-byte stage is 64 k, and half of the tile's N rows are the lo halves of the other half's channels
+  const double flops = F16 ? 2.0 * BM * (BN / 2) * 64.0 * stages * grid : 2.0 * BM * BN * 32.0 * stages * grid;
   std::printf("%-64s %8.3f ms  %7.1f f32-equivalent TFLOP/s  (%s)\n", name, best, flops / best / 1e9,
               hipGetErrorString(hipGetLastError()));
 }
@@ -173,6 +186,14 @@ int main() {
   run<128, 256, 2, 2, 3, true>("P2 128x256, 4 x (64x128), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
   run<256, 128, 2, 2, 3, true>("P3 256x128, 4 x (128x64), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
   run<128, 256, 2, 2, 2, true>("P4 128x256, 4 x (64x128), 2 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  run<128, 128, 2, 4, 2, false, true>("H0 f16 128x128, 8 x (64x32), 2 stages, 2 WG/CU (product)", 2, src, src_bytes, out);
+  run<128, 128, 2, 4, 2, true, true>("H1 H0 + reads pipelined across the barrier", 2, src, src_bytes, out);
+  run<128, 128, 2, 2, 2, false, true>("H2 f16 128x128, 4 x (64x64), 2 stages, 2 WG/CU", 2, src, src_bytes, out);
+  run<128, 128, 2, 2, 2, true, true>("H3 H2 + pipelined", 2, src, src_bytes, out);
+  run<128, 256, 2, 2, 2, true, true>("H4 f16 128x256, 4 x (64x128), 2 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  run<128, 256, 2, 4, 3, true, true>("H5 f16 128x256, 8 x (64x64), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  run<128, 256, 2, 4, 2, false, true>("H6 f16 128x256, 8 x (64x64), 2 stages, 1 WG/CU, product's loop order", 1, src, src_bytes, out);
+  run<128, 256, 2, 4, 2, true, true>("H7 H6 pipelined", 1, src, src_bytes, out);
   }
   return 0;
 }
