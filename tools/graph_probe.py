@@ -11,7 +11,8 @@ from coupe.dvsg_amd.weights import make_synthetic_weights
 prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
 dev = torch.device("cuda:0")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-H, W = 720, 1280
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 720
+W = int(sys.argv[4]) if len(sys.argv) > 4 else 1280
 net = LocNet(make_synthetic_weights(0))
 x = bench.gpu_windows(B, H, W, 1234, dev)
 u = x[..., 18:].contiguous()
@@ -41,5 +42,6 @@ g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g, stream=side):
     step()
 graph = timed(g.replay)
+print("B=%d %dx%d " % (B, H, W), end="")
 print("%s: plain %.3f ms/step, graph replay %.3f ms/step (%.2f %%), identical output: %s" %
       (prec, plain, graph, 100 * (plain / graph - 1), bool(torch.equal(out, ref) and torch.equal(F, ref_F))))
