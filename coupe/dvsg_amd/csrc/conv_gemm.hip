@@ -710,7 +710,8 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // Split-K when the launch has too few tiles for the 512 resident workgroups (batch 1-2): slices
   // of >= 2 stages, at most 8 per tile, partial tiles + tickets in the caller's scratch.
   // (measured at batch 1, 720p: pays for <= 128 tiles and K rows of >= 4 KiB, i.e. the 3x3 convs of
-  // blocks 3-4 and block 4's 1x1 convs; shorter K loops lose more to the reduction than they gain)
+  // blocks 3-4 and block 4's 1x1 convs; shorter K loops lose more to the reduction than they gain;
+  // round 2, up to 16 / 32 slices per tile: a 512x288 frame takes 1.21 / 1.40 ms instead of 1.09, 720p unchanged)
   if (g_conv_variant != 3 && p.splitk_scratch && (!wide || split) && tiles <= 128 && kt_all >= 32) {
     const int ks = (int)std::min<long>(8, std::min<long>(kResident / tiles, kt_all / 2));
     const size_t need = (size_t)tiles * ks * BM * (split ? 128 : 64) * sizeof(float);
