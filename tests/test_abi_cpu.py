@@ -102,3 +102,32 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def _build_c_demo(tmpdir):
+    """examples/c_abi_demo.c with gcc as C99: the header is C (not only C++) and every entry point the demo uses links."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("gcc / ROCm headers not available")
+    exe = os.path.join(str(tmpdir), "c_abi_demo")
+    libdir = os.path.join(ROOT, "coupe", "dvsg_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L" + libdir, "-ldvsg_amd",
+           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return exe
+
+
+def test_header_is_c99_and_the_c_demo_links(tmp_path):
+    _build_c_demo(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_demo_runs_the_known_answer_tests(tmp_path):
+    import subprocess
+    exe = _build_c_demo(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "all checks passed" in out.stdout
