@@ -49,7 +49,7 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
 int launch_zero_tickets(int *tickets, size_t n, hipStream_t s);
 // conv2 (3x3, Cin -> 64, stride 1/2, pad 1, + bias + ReLU) followed by conv3 (1x1, 64 -> Cout, + bias +
 // residual + ReLU) of a bottleneck unit whose middle width is 64 (block 1), fused: the [M,64]
-// intermediate stays in LDS.  float32 only.
+// intermediate stays in LDS.  float32, "f32s" pieces, or the float16 mode (stacked hi / lo weights).
 struct ConvFused {
   const float *x;      // [B,H,W,Cin]
   const float *wt2;    // [64][9*Cin]
@@ -70,6 +70,9 @@ struct ConvFused {
   // "f32s": x, res / sc_x, y hold float16 pieces (P format) and wt2, wt3, sc_wt are the layers' piece matrices
   // ([rows][K/32][32 hi | 32 lo]); same bytes per value, same addressing (pass them through the float pointers)
   int pieces = 0;
+  // float16 mode: x, res / sc_x, y are float16 tensors and wt2, wt3, sc_wt the layers' stacked [hi | lo] float16 matrices
+  // ([cout/64][128][K], conv_gemm.hip SPLIT), passed through the float pointers
+  int f16 = 0;
 };
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize);
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s);

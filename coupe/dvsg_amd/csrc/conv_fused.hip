@@ -1,5 +1,6 @@
 // conv2 (3x3, 64 -> 64, stride 1 or 2, + BN + ReLU) and conv3 (1x1, 64 -> C_out, + BN + residual +
-// ReLU) of a block-1 bottleneck unit (networks.py:33-34 -> slim bottleneck_v1) as ONE kernel, float32.
+// ReLU) of a block-1 bottleneck unit (networks.py:33-34 -> slim bottleneck_v1) as ONE kernel: float32 (and
+// its "f32s" pieces form) first, the float16 mode's version (conv3x3_1x1_f16_kernel) further down.
 //
 // Why: conv3 with K = 64 is an HBM-bound layer -- it reads the [M,64] tensor conv2 has just written,
 // a residual and writes 4x as many channels, with 2 K stages of matrix-core work per tile -- and
@@ -380,16 +381,296 @@ void conv3x3_1x1_kernel(ConvFusedDev p) {
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// The same fusion for the float16 mode (float16 activations, [hi | lo] float16 weight rows stacked along N,
+// conv_gemm.hip): there every block-1 layer is HBM-bound, and the [M,64] conv2 output, conv3's read of it and, in
+// the opening unit, the [M,256] shortcut tensor are a third of the block's traffic.
+// A 128-byte row is 64 float16 k: one K stage of conv2 is one 3x3 tap of all 64 input channels (9 stages), and
+// conv3 / the shortcut (K = 64) are ONE stage each.  Phase 1: A stages 2 x 16 KiB at 0, stacked weight stages
+// (128 rows: 64 hi, 64 lo) 2 x 16 KiB at 32 KiB; wave (wm, wn) owns 32 pixels x channels [32 wn, 32 wn + 32), hi and
+// lo products in two accumulators that are folded (hi + 2^-11 lo) with the bias and ReLU into the float16 conv2 tile
+// at 0.  Phase 2, per 64 output channels: conv3's stacked weights at 32 KiB (and the shortcut's at 48 KiB, its
+// operand -- the unit's input tile, re-read rather than multiplied in a phase 0: four groups of accumulators would
+// not fit the registers -- at 16 KiB), 8 (+ 8) MFMAs per wave, fold, a 128 x 64 float32 transpose through the
+// weight area, bias + residual + ReLU, 8-byte float16 stores.
+// ----------------------------------------------------------------------------------------
+struct ConvFusedF16Dev {
+  const _Float16 *x;     // [B,H,W,Cin]
+  const _Float16 *wt2;   // conv2, stacked [128][9*Cin]
+  const float *bias2;    // [64]
+  const _Float16 *wt3;   // conv3, stacked [Cout/64][128][64]
+  const float *bias3;    // [Cout]
+  const _Float16 *res;   // residual [B,res_H,res_W,Cout]; RES == 3: the unit's input [M,64]
+  const _Float16 *wts;   // RES == 3: shortcut, stacked [Cout/64][128][64]
+  const float *biass;    // RES == 3: [Cout]
+  _Float16 *y;           // [B,Ho,Wo,Cout]
+  int H, W, Cin, Ho, Wo, Cout;
+  int stride;
+  int res_H, res_W, res_stride;
+  int M, mtiles;
+};
+
+template <int RES>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv3x3_1x1_f16_kernel(ConvFusedF16Dev p) {
+  constexpr int NW = 8;
+  constexpr float kLoScale = 1.0f / 2048.0f;
+  __shared__ __attribute__((aligned(16))) char lds[65536];
+  char *As = lds;           // phase 1: 2 x 16 KiB activation stages
+  char *Bs = lds + 32768;   // phase 1: 2 x 16 KiB stacked weight stages
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow8 = lane >> 3, lpos = lane & 7;
+  const int sw = (r >> 1) & 7;
+  const int K1 = 9 * p.Cin;
+  const int KT = K1 / 64;   // >= 9
+
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  const int m0 = xcd_remap(blockIdx.x, p.mtiles) * BM;
+
+  // ---------------------------------------------------------------- phase 1: conv2 tile 128 pixels x 64 channels
+  long a_off[2];
+  unsigned a_mask[2];
+  const _Float16 *wsrc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + NW * i) + lrow8;
+    const int chunk = lpos ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    const int mm = m < p.M ? m : 0;
+    const int wo = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int ho = t % p.Ho;
+    const int b = t / p.Ho;
+    const int hi0 = ho * p.stride - 1, wi0 = wo * p.stride - 1;
+    a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + 8 * chunk;
+    unsigned mk = 0;
+    if (m < p.M) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (hi0 + q >= 0 && hi0 + q < p.H) mk |= 1u << q;
+        if (wi0 + q >= 0 && wi0 + q < p.W) mk |= 16u << q;
+      }
+    }
+    a_mask[i] = mk;
+    wsrc[i] = p.wt2 + (size_t)row * K1 + 8 * chunk;   // stacked weight row `row` (0..127)
+  }
+  int s_kh = 0, s_kw = 0, s_c0 = 0;
+  auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+    const _Float16 *xa = p.x + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+    const int wk = (s_kh * 3 + s_kw) * p.Cin + s_c0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
+      const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16f);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + wk), (lptr_t)(Bs + (buf * 128 + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
+    if (++s_kw == 3) {
+      s_kw = 0;
+      if (++s_kh == 3) {
+        s_kh = 0;
+        s_c0 += 64;
+      }
+    }
+  };
+  floatx16 acc_hi, acc_lo;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc_hi[q] = acc_lo[q] = 0.f;
+  // one 64-k stage: A rows at a_row, stacked weight rows at b_row (hi) and b_row + 64 rows (lo)
+  auto mma_stage = [&](const char *a_row, const char *b_row) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int co = 16 * ((2 * kb + h) ^ sw);
+      const halfx8 a = *reinterpret_cast<const halfx8 *>(a_row + co);
+      const halfx8 bh = *reinterpret_cast<const halfx8 *>(b_row + co);
+      const halfx8 bl = *reinterpret_cast<const halfx8 *>(b_row + 64 * ROWB + co);
+      acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc_hi, 0, 0, 0);
+      acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc_lo, 0, 0, 0);
+    }
+  };
+  auto compute_stage = [&](int buf) __attribute__((always_inline)) {
+    mma_stage(As + (buf * BM + wm * 32 + r) * ROWB, Bs + (buf * 128 + wn * 32 + r) * ROWB);
+  };
+  // 16 KiB of 128 rows x 128 bytes (a K = 64 operand), rows at src + row x row_elems, into lds + dst
+  auto issue_rows = [&](const _Float16 *src, size_t row_elems, int dst, bool by_pixel) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 8 * (wave + NW * i) + lrow8;
+      size_t rr = row;
+      if (by_pixel) rr = m0 + row < p.M ? m0 + row : p.M - 1;   // the unit's input tile: dense [M,64]
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + rr * row_elems + 8 * (lpos ^ ((row >> 1) & 7))),
+                                       (lptr_t)(lds + dst + 8 * (wave + NW * i) * ROWB), 16, 0, 0);
+    }
+  };
+  issue_stage(0);
+  issue_stage(1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  compute_stage(0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 1; kt < KT - 1; ++kt) {
+    __syncthreads();
+    issue_stage((kt + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_stage(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  // the stage buffers not used by the last stage take phase 2's first operands
+  const int last = (KT - 1) & 1;
+  if (RES == 3) {
+    issue_rows(p.res, 64, last == 0 ? 16384 : 0, true);                    // (KT = 9 for block 1: last == 0, the tile at 16 KiB)
+    issue_rows(p.wts, 64, last == 0 ? 49152 : 32768, false);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  compute_stage(last);
+
+  // ---------------------------------------------------------------- the tile becomes conv3's left operand (float16)
+  const float bmid = p.bias2[32 * wn + r];
+  __syncthreads();  // everyone is done with the phase-1 stage buffers
+  // LDS map of phase 2 (KT odd, last == 0): conv2 tile at 0, the unit's input tile at 16 KiB, conv3 weights of the
+  // group at 32 KiB, shortcut weights at 48 KiB.  (KT even would swap the roles of the halves; block 1 has KT = 9.)
+  const int T2 = last == 0 ? 0 : 16384, SX = last == 0 ? 16384 : 0;
+  const int W3 = last == 0 ? 32768 : 49152, WS = last == 0 ? 49152 : 32768;
+  issue_rows(p.wt3, 64, W3, false);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int R = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    const int k2 = 32 * wn + r;
+    const float v = fmaxf(acc_hi[q] + acc_lo[q] * kLoScale + bmid, 0.f);
+    *reinterpret_cast<_Float16 *>(lds + T2 + R * ROWB + 16 * ((k2 >> 3) ^ ((R >> 1) & 7)) + 2 * (k2 & 7)) = (_Float16)v;
+  }
+
+  // ---------------------------------------------------------------- phase 2: conv3 (+ shortcut), 64 channels at a time
+  float *Cs = reinterpret_cast<float *>(lds + 32768);   // 128 rows x 64 channels
+  const int col4 = tid & 15, row0 = tid >> 4;            // 16 float4 per row, 32 rows per pass
+  const int ngroups = p.Cout / 64;
+  for (int g = 0; g < ngroups; ++g) {
+    // residual of the thread's rows: in flight under the weight DMA and the MFMAs
+    float4 rv[4];
+    const int n = 64 * g + 4 * col4;
+    if (RES != 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mr = m0 + row0 + 32 * i;
+        const int m = mr < p.M ? mr : p.M - 1;
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(p.res + roff);
+      }
+    }
+    float4 bias4 = *reinterpret_cast<const float4 *>(p.bias3 + n);
+    if (RES == 3) {
+      const float4 bs = *reinterpret_cast<const float4 *>(p.biass + n);
+      bias4.x += bs.x; bias4.y += bs.y; bias4.z += bs.z; bias4.w += bs.w;
+    }
+    // the group's weights (and, first group, the conv2 tile written above) have landed: only the residual loads,
+    // issued after them, may still be outstanding
+    if (RES != 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc_hi[q] = acc_lo[q] = 0.f;
+    mma_stage(lds + T2 + (wm * 32 + r) * ROWB, lds + W3 + (wn * 32 + r) * ROWB);
+    if (RES == 3) mma_stage(lds + SX + (wm * 32 + r) * ROWB, lds + WS + (wn * 32 + r) * ROWB);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the weights have been read: their area becomes the transpose buffer
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      Cs[(wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 64 + wn * 32 + r] = acc_hi[q] + acc_lo[q] * kLoScale;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(Cs + (row0 + 32 * i) * 64 + 4 * col4);
+    if (g + 1 < ngroups) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // the transpose buffer has been read: the next group's weights may land in it
+      asm volatile("" ::: "memory");
+      issue_rows(p.wt3 + (size_t)(g + 1) * 128 * 64, 64, W3, false);
+      if (RES == 3) issue_rows(p.wts + (size_t)(g + 1) * 128 * 64, 64, WS, false);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + row0 + 32 * i;
+      if (m < p.M) {
+        float4 o = v[i];
+        o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w;
+        if (RES != 3) {
+          o.x += rv[i].x; o.y += rv[i].y; o.z += rv[i].z; o.w += rv[i].w;
+        }
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        store4(p.y + (size_t)m * p.Cout + n, o);
+      }
+    }
+  }
+}
+
 int g_fuse_conv = 1;  // dvsg_debug_set_option("fuse_conv", 0) turns the fused block-1 path off
 
 }  // namespace
 
 void set_fuse_conv(int v) { g_fuse_conv = v; }
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize) {
+  if (prec == kF16) return g_fuse_conv != 0 && ksize == 3 && Cmid == CMID && Cin % 64 == 0 && Cout % 64 == 0;
   return g_fuse_conv != 0 && (prec == kF32 || prec == kF32S) && ksize == 3 && Cmid == CMID && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0;
 }
 
+static int launch_conv3x3_1x1_f16(const ConvFused &p, hipStream_t s) {
+  DVSG_REQUIRE(p.Cin % 64 == 0 && p.Cin >= 64 && p.Cout % 64 == 0, "conv3x3_1x1 (float16): Cin=%d and Cout=%d must be multiples of 64",
+               p.Cin, p.Cout);
+  const bool sc = p.sc_x != nullptr;
+  DVSG_REQUIRE(p.res || sc, "conv3x3_1x1: the unit output needs its residual");
+  DVSG_REQUIRE(!sc || (p.sc_wt && p.sc_bias && p.sc_cin == CSC && p.stride == 1),
+               "conv3x3_1x1 (float16): fused shortcut needs %d input channels and stride 1 (got %d, %d)", CSC, p.sc_cin, p.stride);
+  const long M = (long)p.B * p.Ho * p.Wo;
+  DVSG_REQUIRE(M > 0 && M < (1L << 31) - BM, "conv3x3_1x1: M=%ld out of range", M);
+  ConvFusedF16Dev d;
+  d.x = reinterpret_cast<const _Float16 *>(p.x);
+  d.wt2 = reinterpret_cast<const _Float16 *>(p.wt2); d.bias2 = p.bias2;
+  d.wt3 = reinterpret_cast<const _Float16 *>(p.wt3); d.bias3 = p.bias3;
+  d.res = reinterpret_cast<const _Float16 *>(sc ? p.sc_x : p.res);
+  d.wts = reinterpret_cast<const _Float16 *>(p.sc_wt); d.biass = p.sc_bias;
+  d.y = reinterpret_cast<_Float16 *>(p.y);
+  d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
+  d.stride = p.stride;
+  d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;
+  d.M = (int)M;
+  d.mtiles = (int)((M + BM - 1) / BM);
+  const int res = sc ? 3 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
+  ProfScope prof(kClsFused, s,
+                 2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID + (sc ? 2.0 * (double)M * p.Cout * CSC : 0.0),
+                 2.0 * ((double)p.B * p.H * p.W * p.Cin + 2.0 * CMID * 9 * p.Cin + 2.0 * p.Cout * CMID +
+                        (sc ? (double)M * CSC + 2.0 * p.Cout * CSC + (double)M * p.Cout : 2.0 * (double)M * p.Cout)));
+  const dim3 grid(d.mtiles), block(512);
+  if (res == 1) hipLaunchKernelGGL((conv3x3_1x1_f16_kernel<1>), grid, block, 0, s, d);
+  else if (res == 2) hipLaunchKernelGGL((conv3x3_1x1_f16_kernel<2>), grid, block, 0, s, d);
+  else hipLaunchKernelGGL((conv3x3_1x1_f16_kernel<3>), grid, block, 0, s, d);
+  return check_launch("conv3x3_1x1_f16_kernel");
+}
+
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
+  if (p.f16) return launch_conv3x3_1x1_f16(p, s);
   DVSG_REQUIRE(p.Cin % 32 == 0 && p.Cin >= 64 && p.Cout % 128 == 0, "conv3x3_1x1: Cin=%d must be a multiple of 32 (>= 64), Cout=%d of 128",
                p.Cin, p.Cout);
   const bool sc = p.sc_x != nullptr;  // the residual is the 1x1 shortcut conv of sc_x, computed in the kernel

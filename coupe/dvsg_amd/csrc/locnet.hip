@@ -355,7 +355,8 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
     const int ho = (h - 1) / u.stride + 1, wo = (w - 1) / u.stride + 1;
     const void *res = X;
     int res_h = h, res_w = w, res_stride = u.stride;
-    const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize);
+    // (float16 mode: the fused kernel multiplies against the stacked hi / lo weights only)
+    const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) && (prec != kF16 || g_f16_split);
     // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
     const bool fuse_sc = fuse23 && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
                          g_fuse_shortcut;
@@ -368,8 +369,11 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
     if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
       const bool pcs = prec == kF32S;
-      auto wts_of = [&](const ConvLayer &L) { return pcs ? reinterpret_cast<const float *>(L.wt32s) : L.wt; };
+      auto wts_of = [&](const ConvLayer &L) {
+        return pcs ? reinterpret_cast<const float *>(L.wt32s) : prec == kF16 ? reinterpret_cast<const float *>(L.wt16s) : L.wt;
+      };
       f.pieces = pcs;
+      f.f16 = prec == kF16;
       f.x = reinterpret_cast<const float *>(ws.r1); f.wt2 = wts_of(u.c2); f.bias2 = u.c2.bias; f.wt3 = wts_of(u.c3); f.bias3 = u.c3.bias;
       f.res = static_cast<const float *>(res); f.y = reinterpret_cast<float *>(Y);
       f.B = B; f.H = h; f.W = w; f.Cin = u.c2.cin; f.Ho = ho; f.Wo = wo; f.Cout = u.c3.cout;

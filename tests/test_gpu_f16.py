@@ -152,3 +152,29 @@ def test_conv_gemm_f16_layer(net):
             _lib.call("dvsg_conv_gemm_f16", xs.data_ptr(), w32.half().contiguous().data_ptr(), bias.data_ptr(), rs.data_ptr(),
                       y16.data_ptr(), Bs, h, w, cin, cout, k, stride, 1, 1, 0, 0, torch.cuda.current_stream().cuda_stream)
             assert float((ys.float() - ref).abs().mean()) <= float((y16.float() - ref).abs().mean())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 70, 100), (1, 33, 47), (3, 64, 96)])
+def test_f16_fused_block1_kernel_matches_the_unfused_layers(net, B, H, W):
+    """Block 1's conv2 + conv3 (+ the opening unit's shortcut conv) run as one kernel in the float16 mode too
+    (conv_fused.hip); against the same layers as separate launches only the rounding sites of the float32 sums move
+    (K order of conv2, one fold of hi + lo instead of two)."""
+    from coupe.dvsg_amd import _lib
+    x = inputs.window_frames(321, B, H, W)
+    try:
+        _lib.call("dvsg_debug_set_option", b"fuse_conv", 0)
+        plain = [net.tap(x, s, precision="f16").cpu().numpy() for s in (2, 3, 4)]
+        F_plain = net.forward(x, precision="f16").cpu().numpy()
+    finally:
+        _lib.call("dvsg_debug_set_option", b"fuse_conv", 1)
+    fused = [net.tap(x, s, precision="f16").cpu().numpy() for s in (2, 3, 4)]
+    F_fused = net.forward(x, precision="f16").cpu().numpy()
+    for name, a, b in zip(("unit_1 (shortcut fused)", "unit_2", "unit_3 (stride 2)"), fused, plain):
+        assert a.shape == b.shape
+        rel = np.abs(a - b).max() / np.abs(b).max()
+        assert rel < 2e-3, "%s: %.3g" % (name, rel)      # float16 activations: 4.9e-4 per rounding
+        # (the fused opening unit keeps its shortcut in the float32 accumulators where the separate launch stores it as
+        # float16: outputs one float16 ulp apart, on average a third of an ulp -- which the following units inherit)
+        assert np.abs(a - b).mean() / np.abs(b).mean() < 1e-3, name
+    assert np.abs(F_fused - F_plain).max() < 5e-5     # the bound of either path against the oracle at these sizes
+    assert np.array_equal(F_fused, net.forward(x, precision="f16").cpu().numpy())   # deterministic
