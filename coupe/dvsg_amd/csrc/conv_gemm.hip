@@ -45,7 +45,8 @@
 // tile of two [hi | lo] channel groups with a ring of three LDS stages, one workgroup per CU, is 20 % faster in that
 // loop.  Built into this kernel (BN = 256, plain tiles) it LOST 4.5 % end to end at 720p and 6 % at 4K (3x3 class 2.72
 // vs 2.54 ms): with a single workgroup per CU nobody multiplies while a tile's prologue, first-stage wait and 133 KB
-// transpose run.  Removed again.)
+// transpose run.  Removed again; what keeps two workgroups per CU at the same bytes per product is a 256 x 128 tile
+// with 64-byte K stages: conv_gemm_wide16.hip, which launch_conv_gemm picks for float16 launches of >= 256 such tiles.)
 //
 // Where the main loop's time goes (ablations at batch 16, 720p, plain tiles): with the LDS-DMA
 // removed the 52 launches of a step take 17.8 ms instead of 19.6, and exactly the same with the DMA
@@ -577,7 +578,9 @@ void conv_gemm_kernel(ConvGemmDev p) {
 }
 
 int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = auto, 1 = 4 waves, 2 = 8 waves,
-                         // 3 = no split-K, 4 = 64-wide tiles only, 6 = no stream-K tail
+                         // 3 = no split-K, 4 = 64-wide tiles only, 5 = no 256 x 128 float16 tiles, 6 = no stream-K tail
+long g_wide16_min_tiles = 256;   // float16 mode: 256 x 128 tiles from this many of them (half a round of 512 workgroups: measured
+                                 // never slower from there, batch 1 .. 16 at 288p .. 4K; 128 and below lose at batch 1-2)
 
 template <typename T, int BN, int WM, int WN, int KS, int MODE, bool SPLIT = false>
 int launch_cfg(const ConvGemmDev &d, int blocks, bool relu, int res, hipStream_t s) {
@@ -646,6 +649,7 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
 }  // namespace
 
 void set_conv_variant(int v) { g_conv_variant = v; }
+void set_wide16_min_tiles(int v) { g_wide16_min_tiles = v; }
 
 namespace {
 __global__ __launch_bounds__(256) void zero_tickets_kernel(int *__restrict__ t, size_t n) {
@@ -703,6 +707,8 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // its whole panel past the 4 MB L2 (1.2 GB per launch).  With mt fastest an XCD stays on one or
   // two panels and re-reads the (much smaller) activations instead.
   d.mt_fast = d.ntiles > 1 && (size_t)(wide ? 128 : 64) * d.K * elem_size(p.prec) >= ((size_t)2 << 20);
+  // float16 mode: a launch of several rounds of tiles runs in the 256 x 128 / 64-byte-stage geometry (conv_gemm_wide16.hip)
+  if (split && g_conv_variant != 5 && (long)((M + 255) / 256) * (p.Cout / 64) >= g_wide16_min_tiles) return launch_conv_wide16(p, s);
   d.ksplit = 1;
   d.slabs = static_cast<float *>(p.splitk_scratch);
   d.counters = p.splitk_counters;

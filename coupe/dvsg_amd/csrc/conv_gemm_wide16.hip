@@ -1,0 +1,265 @@
+// The float16 mode's implicit-GEMM convolution (conv_gemm.hip: float16 activations against [hi | lo] float16 weight
+// rows stacked along N) in a second tile geometry, for launches that are several rounds of tiles:
+//
+//     256 pixels x 128 weight rows ([64 hi | 64 lo] of one 64-channel group), K stages of 64 BYTES (32 k).
+//
+// Why: that loop is bound by the L2 -> LDS stream, not by the matrix pipe, the LDS or HBM -- in isolation every
+// 128 x 128 configuration of it (4 or 8 waves, fragment reads pipelined or not) runs at the same ~15 TB/s of LDS-DMA,
+// 500 algorithmic TFLOP/s (tools/pieces_loop_bench.hip, H0-H3).  A 256 x 128 tile moves a quarter fewer bytes per
+// product; with 128-byte stages it needs 96 KB of LDS and one workgroup per CU, and that version (as 128 x 256) lost
+// 4.5-6 % in the product because nothing multiplies during a tile's prologue, first-stage wait and transpose.
+// Halving the stage depth instead keeps the stage at 24 KB, the ring of two at 48 KB and TWO workgroups per CU:
+// 660 TFLOP/s in the isolated loop (H8), +32 %.
+//
+// Layout of a stage: rows of 64 bytes = 4 chunks of 16 bytes; an LDS-DMA wave-instruction writes 64 x 16 B = 16 rows
+// linearly, lane -> row 16 g + lane / 4, chunk position lane % 4, which receives global chunk pos ^ ((row >> 2) & 3).
+// A fragment read (ds_read_b128, 16 lanes per pass = rows r .. r + 15 of one MFMA operand) then hits bank groups
+// 4 (row & 3) + (chunk ^ (row >> 2) & 3): all 16 distinct.  Wave (wm, wn), 4 x 2: pixels [64 wm, 64 wm + 64) x channels
+// [32 wn, 32 wn + 32) of the group, hi and lo rows in separate accumulators (two 32-pixel blocks each: 64 registers),
+// 8 MFMAs (v_mfma_f32_32x32x16_f16) per wave and stage.  Epilogue: hi + 2^-11 lo through a 128-row float32 transpose in the
+// (idle) stage buffers, two rounds, then bias (+ residual) (+ ReLU) and 8-byte float16 stores.
+// Plain tiles only (one workgroup per tile, no split-K / stream-K): launch_conv_gemm picks this kernel for the big
+// launches and keeps conv_gemm_kernel for the rest.
+#include "cnn_device.h"
+#include "cnn_kernels.h"
+
+namespace dvsg {
+namespace {
+
+constexpr int WBM = 256;     // pixels per tile
+constexpr int WBN = 128;     // stacked weight rows per tile (64 output channels)
+constexpr int WROWB = 64;    // bytes of k per row and stage (32 float16)
+constexpr int WBKE = 32;     // k elements per stage
+
+__device__ const floatx4 g_zero16w = {0.f, 0.f, 0.f, 0.f};
+
+struct ConvWide16Dev {
+  const _Float16 *x, *wt, *res;
+  const float *bias;
+  _Float16 *y;
+  int H, W, Cin, Ho, Wo, Cout;
+  int stride, pad;
+  int res_H, res_W, res_stride;
+  int M, K, mtiles, ntiles;
+};
+
+template <int KS, bool RELU, int RES>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv_wide16_kernel(ConvWide16Dev p) {
+  constexpr int NW = 8, MI = 2;
+  constexpr int AG = WBM / 16 / NW;   // 2 LDS-DMA instructions (16 rows each) per wave and stage for the pixels
+  constexpr int PER = AG + 1;         // + 1 for the 128 weight rows
+  constexpr float kLoScale = 1.0f / 2048.0f;
+  __shared__ __attribute__((aligned(16))) char lds[2 * (WBM + WBN) * WROWB];   // 48 KiB
+  char *As = lds;
+  char *Bs = lds + 2 * WBM * WROWB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow = lane >> 2, lpos = lane & 3;
+  const int sw = (r >> 2) & 3;   // rows of a fragment are 32-aligned + r
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  // nt fastest: the n-tiles of a pixel tile run back to back on one XCD and re-read its activations out of L2
+  const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int m0 = mt * WBM;
+
+  long a_off[AG];
+  unsigned a_mask[AG];
+  const bool dense = KS == 1 && p.stride == 1;   // a 1x1 / stride 1 layer is a row-major GEMM (conv_gemm.hip)
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    const int row = 16 * (wave + NW * i) + lrow;
+    const int chunk = lpos ^ ((row >> 2) & 3);
+    const int m = m0 + row;
+    const int mm = m < p.M ? m : 0;
+    if (dense) {
+      a_off[i] = (long)mm * p.Cin + 8 * chunk;
+      a_mask[i] = m < p.M ? 0x11u : 0u;
+      continue;
+    }
+    const int wo = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int ho = t % p.Ho;
+    const int b = t / p.Ho;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + 8 * chunk;
+    unsigned mk = 0;
+    if (m < p.M) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        if (hi0 + q >= 0 && hi0 + q < p.H) mk |= 1u << q;
+        if (wi0 + q >= 0 && wi0 + q < p.W) mk |= 16u << q;
+      }
+    }
+    a_mask[i] = mk;
+  }
+  const _Float16 *wsrc;
+  {
+    const int row = 16 * wave + lrow;   // stacked weight row of the tile (0..127)
+    wsrc = p.wt + ((size_t)nt * WBN + row) * p.K + 8 * (lpos ^ ((row >> 2) & 3));
+  }
+  // K order as in conv_gemm.hip: channel chunk outer, the KS x KS taps inner
+  int s_kh = 0, s_kw = 0, s_c0 = 0;
+  auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+    const _Float16 *xa = p.x + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+    const int wk = KS > 1 ? (s_kh * KS + s_kw) * p.Cin + s_c0 : s_c0;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
+      const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16w);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * WBM + 16 * (wave + NW * i)) * WROWB), 16, 0, 0);
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + wk), (lptr_t)(Bs + (buf * WBN + 16 * wave) * WROWB), 16, 0, 0);
+    if (KS > 1) {
+      if (++s_kw == KS) {
+        s_kw = 0;
+        if (++s_kh == KS) {
+          s_kh = 0;
+          s_c0 += WBKE;
+        }
+      }
+    } else {
+      s_c0 += WBKE;
+    }
+  };
+  floatx16 acc_hi[MI], acc_lo[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc_hi[mi][q] = acc_lo[mi][q] = 0.f;
+  auto compute_stage = [&](int buf) __attribute__((always_inline)) {
+    const char *a_base = As + (buf * WBM + wm * 64 + r) * WROWB;
+    const char *b_base = Bs + (buf * WBN + wn * 32 + r) * WROWB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int co = 16 * ((2 * t + h) ^ sw);
+      const halfx8 bh = *reinterpret_cast<const halfx8 *>(b_base + co);
+      const halfx8 bl = *reinterpret_cast<const halfx8 *>(b_base + 64 * WROWB + co);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const halfx8 a = *reinterpret_cast<const halfx8 *>(a_base + mi * 32 * WROWB + co);
+        acc_hi[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc_hi[mi], 0, 0, 0);
+        acc_lo[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc_lo[mi], 0, 0, 0);
+      }
+    }
+  };
+
+  const int KT = p.K / WBKE;   // >= 2 (Cin % 64 == 0)
+  issue_stage(0);
+  issue_stage(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  compute_stage(0);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 1; kt < KT - 1; ++kt) {
+    __syncthreads();   // vmcnt(0): stage kt has landed; everyone has read stage kt - 1
+    issue_stage((kt + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_stage(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  compute_stage((KT - 1) & 1);
+
+  // ---- epilogue: 64 output channels, two rounds of 128 pixels through a [128][64] float32 transpose
+  float *Cs = reinterpret_cast<float *>(lds);
+  const int col4 = tid & 15, row0 = tid >> 4;   // 16 float4 per row, 32 rows per pass
+  const int n = nt * 64 + 4 * col4;
+  const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+  for (int rho = 0; rho < 2; ++rho) {
+    float4 rv[4];
+    if (RES != 0) {   // residual of this round's rows: in flight under the two barriers and the transpose
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mr = m0 + 128 * rho + row0 + 32 * i;
+        const int m = mr < p.M ? mr : p.M - 1;
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(p.res + roff);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the stage buffers (first round) / the previous round's rows have been read
+    asm volatile("" ::: "memory");
+    if ((wm >> 1) == rho) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          Cs[((wm & 1) * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 64 + wn * 32 + r] =
+              acc_hi[mi][q] + acc_lo[mi][q] * kLoScale;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + 32 * i;
+      const int m = m0 + 128 * rho + row;
+      if (m < p.M) {
+        float4 v = *reinterpret_cast<const float4 *>(Cs + row * 64 + 4 * col4);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (RES != 0) {
+          v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+        }
+        if (RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        store4(p.y + (size_t)m * p.Cout + n, v);
+      }
+    }
+  }
+}
+
+template <int KS>
+int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
+  const dim3 grid(d.mtiles * d.ntiles), block(512);
+#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_wide16_kernel<KS, R, Q>), grid, block, 0, s, d)
+  if (relu) {
+    if (res == 0) DVSG_LAUNCH(true, 0);
+    else if (res == 1) DVSG_LAUNCH(true, 1);
+    else DVSG_LAUNCH(true, 2);
+  } else {
+    if (res == 0) DVSG_LAUNCH(false, 0);
+    else if (res == 1) DVSG_LAUNCH(false, 1);
+    else DVSG_LAUNCH(false, 2);
+  }
+#undef DVSG_LAUNCH
+  return check_launch("conv_wide16_kernel");
+}
+
+}  // namespace
+
+// p: a float16 layer with stacked weights (p.wsplit), Cin % 64 == 0, Cout % 64 == 0; the caller has opened the ProfScope
+int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  ConvWide16Dev d;
+  d.x = static_cast<const _Float16 *>(p.x); d.wt = static_cast<const _Float16 *>(p.wt);
+  d.res = static_cast<const _Float16 *>(p.res); d.bias = p.bias; d.y = static_cast<_Float16 *>(p.y);
+  d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
+  d.stride = p.stride; d.pad = p.pad;
+  d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;
+  d.M = (int)M;
+  d.K = p.ksize * p.ksize * p.Cin;
+  d.mtiles = (int)((M + WBM - 1) / WBM);
+  d.ntiles = p.Cout / 64;
+  const int res = !p.res ? 0 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
+  return p.ksize == 3 ? launch_ks<3>(d, p.relu != 0, res, s) : launch_ks<1>(d, p.relu != 0, res, s);
+}
+
+}  // namespace dvsg

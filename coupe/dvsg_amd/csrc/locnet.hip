@@ -677,6 +677,10 @@ int dvsg_debug_set_option(const char *name, int value) {
     set_conv_variant(value);
     return DVSG_OK;
   }
+  if (std::strcmp(name, "wide16_min_tiles") == 0) {
+    set_wide16_min_tiles(value);
+    return DVSG_OK;
+  }
   if (std::strcmp(name, "conv1_variant") == 0) {
     set_conv1_variant(value);
     return DVSG_OK;

@@ -178,3 +178,60 @@ def test_f16_fused_block1_kernel_matches_the_unfused_layers(net, B, H, W):
         assert np.abs(a - b).mean() / np.abs(b).mean() < 1e-3, name
     assert np.abs(F_fused - F_plain).max() < 5e-5     # the bound of either path against the oracle at these sizes
     assert np.array_equal(F_fused, net.forward(x, precision="f16").cpu().numpy())   # deterministic
+
+
+def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
+    """conv_gemm_wide16.hip (256 x 128 tiles, 64-byte K stages: what dvsg_conv_gemm_f16s runs for launches of >= 256
+    tiles) forced onto small ragged layers -- M not a multiple of 256, stride 2, residual of the output's shape and the
+    subsampled `shortcut`, no residual, no ReLU -- against float32 math on the unrounded weights, and against the
+    128 x 128 kernel (same products; the K order within a layer differs by the stage depth)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+    cases = [  # k, stride, cin, cout, B, h, w, residual mode (0 none, 1 same shape, 2 subsampled input-sized), relu
+        (3, 1, 64, 64, 3, 21, 29, 1, 1), (3, 2, 128, 128, 2, 23, 31, 0, 1), (1, 1, 256, 128, 5, 9, 13, 1, 0),
+        (1, 1, 64, 256, 2, 37, 41, 2, 1), (3, 1, 256, 256, 1, 16, 16, 1, 1), (1, 1, 512, 64, 7, 5, 3, 0, 1)]
+    try:
+        for k, stride, cin, cout, B, h, w, rmode, relu in cases:
+            K = k * k * cin
+            ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+            x = (torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3).half()
+            w32 = (torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)
+            hi = w32.half()
+            lo = ((w32 - hi.float()) * 2048.0).half()
+            ws = torch.stack([hi.reshape(cout // 64, 64, K), lo.reshape(cout // 64, 64, K)], 1).reshape(2 * cout, K).contiguous()
+            bias = torch.rand((cout,), generator=g, device=dev) - 0.5
+            res_stride = 1
+            if rmode == 1:
+                res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5).half()
+                res_at = res
+            elif rmode == 2:   # residual tensor twice the output's size, sampled at every other pixel
+                res_stride = 2
+                res = (torch.rand((B, 2 * (ho - 1) + 1, 2 * (wo - 1) + 1, cout), generator=g, device=dev) - 0.5).half()
+                res_at = res[:, ::2, ::2, :]
+            else:
+                res, res_at = None, None
+            outs = {}
+            for thr in (1, 1 << 30):   # wide tiles for everything / never
+                _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", thr)
+                y = torch.full((B, ho, wo, cout), float("nan"), device=dev, dtype=torch.float16)
+                _lib.call("dvsg_conv_gemm_f16s", x.data_ptr(), ws.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else 0,
+                          y.data_ptr(), B, h, w, cin, cout, k, stride, relu, res_stride, scratch.data_ptr(), scratch.numel(), st)
+                outs[thr] = y.float()
+            w4 = w32.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+            if res_at is not None:
+                ref = ref + res_at.float()
+            if relu:
+                ref = torch.relu(ref)
+            scale = max(1.0, float(ref.abs().max()))
+            case = (k, stride, cin, cout, B, h, w, rmode, relu)
+            assert bool(torch.isfinite(outs[1]).all()), case
+            assert float((outs[1] - ref).abs().max()) < 1.2e-3 * scale, case          # float16 rounding of the output
+            assert float((outs[1] - outs[1 << 30]).abs().max()) < 1.0e-3 * scale, case   # one float16 ulp of the output
+            assert float((outs[1] - outs[1 << 30]).abs().mean()) < 2e-5 * scale, case
+    finally:
+        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)

@@ -18,6 +18,8 @@
 // float16 mode loop (H*): 128 x 128 tiles 495-505 whatever the wave layout (the L2 -> LDS stream, ~15 TB/s, bounds it);
 // 128 x 256 tiles, 3 stages, 1 workgroup per CU 570-610 -- but built into conv_gemm_kernel that configuration lost
 // 4.5-6 % end to end (nobody multiplies during a tile's prologue / epilogue with one workgroup per CU).
+// H8-H10: 256 x 128 tiles with 64-byte (32-k) stages, 48 KB of LDS, TWO workgroups per CU: 620-665 -- the geometry of
+// conv_gemm_wide16.hip (+2.7 % end to end at 720p batch 16, +5.7 % at 4K batch 32).
 //   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
 #include <hip/hip_runtime.h>
 
@@ -28,17 +30,17 @@ typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-constexpr int ROWB = 128;
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128>
 __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stages, const char *src, size_t src_bytes) {
   constexpr int NW = WM * WN, MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int PER = (BM + BN) / 8 / NW;   // LDS-DMA instructions per wave and stage
+  constexpr int PER = (BM + BN) * ROWB / 1024 / NW;   // LDS-DMA instructions (1 KiB each) per wave and stage
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
-  const int sw = (r >> 1) & 7;
+  // 128-byte rows: 8 chunks, chunk ^ (row >> 1) & 7; 64-byte rows (F16 only): 4 chunks, chunk ^ (row >> 2) & 3
+  const int sw = ROWB == 128 ? (r >> 1) & 7 : (r >> 2) & 3;
   floatx16 acc[MI][NI];
   for (int mi = 0; mi < MI; ++mi)
     for (int ni = 0; ni < NI; ++ni)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
   // F16 (the float16 mode: f16 activations, [hi | lo] weight rows stacked along N): four 16-k steps per 128-byte
   // stage, one fragment per operand block and one MFMA per block pair; else the pieces loop (two steps, hi / lo
   // fragments, three MFMAs per block pair)
-  constexpr int TSTEPS = F16 ? 4 : 2;
+  constexpr int TSTEPS = F16 ? ROWB / 32 : 2;
   struct Frags {
     halfx8 ahi[MI], alo[F16 ? 1 : MI], bhi[NI], blo[F16 ? 1 : NI];
   };
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
   if (sum == 12345.678f) out[tid] = sum;  // keep the accumulators live
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128>
 void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, float *out) {
   const int stages = 72, grid = 256 * wgs_per_cu * 6;
   const size_t lds = (size_t)NS * (BM + BN) * ROWB;
-  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16>;
+  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16, ROWB>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -168,7 +170,7 @@ void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, fl
     if (rep >= 4 && ms < best) best = ms;
   }
   // F16: a 128-byte stage is 64 k, and half of the tile's N rows are the lo halves of the other half's channels
-  const double flops = F16 ? 2.0 * BM * (BN / 2) * 64.0 * stages * grid : 2.0 * BM * BN * 32.0 * stages * grid;
+  const double flops = F16 ? 2.0 * BM * (BN / 2) * (ROWB / 2.0) * stages * grid : 2.0 * BM * BN * 32.0 * stages * grid;
   std::printf("%-64s %8.3f ms  %7.1f f32-equivalent TFLOP/s  (%s)\n", name, best, flops / best / 1e9,
               hipGetErrorString(hipGetLastError()));
 }
@@ -194,6 +196,9 @@ int main() {
   run<128, 256, 2, 4, 3, true, true>("H5 f16 128x256, 8 x (64x64), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
   run<128, 256, 2, 4, 2, false, true>("H6 f16 128x256, 8 x (64x64), 2 stages, 1 WG/CU, product's loop order", 1, src, src_bytes, out);
   run<128, 256, 2, 4, 2, true, true>("H7 H6 pipelined", 1, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, true, 64>("H8 f16 256x128, 8 x (64x64), 64-byte stages, 2 stages, 2 WG/CU", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, true, true, 64>("H9 H8 pipelined", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 3, false, true, 64>("H10 H8 with 3 stages (72 KiB), 2 WG/CU", 2, src, src_bytes, out);
   }
   return 0;
 }
