@@ -15,6 +15,9 @@
 // (two workgroups per CU already cover each other's LDS round trips): the loop itself runs at 52-59 % of the pieces
 // roof, 1.25 us per stage like the product's workgroups; a whole 3x3 layer (310 in the product) then loses its
 // partly filled last round of tiles and the tile prologues / epilogues.
+// P5 / P6 (the pieces loop in the 256 x 128 / 64-byte-stage geometry, two workgroups per CU): 550-560, +12..29 % -- the
+// pieces loop in the product's configuration moves the same 32 KB per stage as the float16 one and sits on the same
+// ~15 TB/s L2 -> LDS stream; not built (an estimated +1.5 % end to end at 720p batch 16 for the f32s precision).
 // float16 mode loop (H*): 128 x 128 tiles 495-505 whatever the wave layout (the L2 -> LDS stream, ~15 TB/s, bounds it);
 // 128 x 256 tiles, 3 stages, 1 workgroup per CU 570-610 -- but built into conv_gemm_kernel that configuration lost
 // 4.5-6 % end to end (nobody multiplies during a tile's prologue / epilogue with one workgroup per CU).
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
   // F16 (the float16 mode: f16 activations, [hi | lo] weight rows stacked along N): four 16-k steps per 128-byte
   // stage, one fragment per operand block and one MFMA per block pair; else the pieces loop (two steps, hi / lo
   // fragments, three MFMAs per block pair)
-  constexpr int TSTEPS = F16 ? ROWB / 32 : 2;
+  constexpr int TSTEPS = F16 ? ROWB / 32 : ROWB / 64;   // pieces: a 64-byte row is one 16-k step (2 hi chunks, 2 lo chunks)
+  constexpr int LO = ROWB / 32;                          // pieces: chunk distance between a value's hi and lo piece
   struct Frags {
     halfx8 ahi[MI], alo[F16 ? 1 : MI], bhi[NI], blo[F16 ? 1 : NI];
   };
@@ -72,12 +76,12 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       f.ahi[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * (g ^ sw));
-      if constexpr (!F16) f.alo[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * ((4 + g) ^ sw));
+      if constexpr (!F16) f.alo[mi] = *reinterpret_cast<const halfx8 *>(a + mi * 32 * ROWB + 16 * ((LO + g) ^ sw));
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       f.bhi[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * (g ^ sw));
-      if constexpr (!F16) f.blo[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * ((4 + g) ^ sw));
+      if constexpr (!F16) f.blo[ni] = *reinterpret_cast<const halfx8 *>(b + ni * 32 * ROWB + 16 * ((LO + g) ^ sw));
     }
   };
   auto mma = [&](const Frags &f) __attribute__((always_inline)) {
@@ -170,7 +174,7 @@ void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, fl
     if (rep >= 4 && ms < best) best = ms;
   }
   // F16: a 128-byte stage is 64 k, and half of the tile's N rows are the lo halves of the other half's channels
-  const double flops = F16 ? 2.0 * BM * (BN / 2) * (ROWB / 2.0) * stages * grid : 2.0 * BM * BN * 32.0 * stages * grid;
+  const double flops = F16 ? 2.0 * BM * (BN / 2) * (ROWB / 2.0) * stages * grid : 2.0 * BM * BN * (ROWB / 4.0) * stages * grid;
   std::printf("%-64s %8.3f ms  %7.1f f32-equivalent TFLOP/s  (%s)\n", name, best, flops / best / 1e9,
               hipGetErrorString(hipGetLastError()));
 }
@@ -188,6 +192,8 @@ int main() {
   run<128, 256, 2, 2, 3, true>("P2 128x256, 4 x (64x128), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
   run<256, 128, 2, 2, 3, true>("P3 256x128, 4 x (128x64), 3 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
   run<128, 256, 2, 2, 2, true>("P4 128x256, 4 x (64x128), 2 stages, 1 WG/CU, pipelined", 1, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, false, 64>("P5 pieces 256x128, 8 x (64x64), 64-byte stages, 2 stages, 2 WG/CU", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 3, false, false, 64>("P6 P5 with 3 stages (72 KiB), 2 WG/CU", 2, src, src_bytes, out);
   run<128, 128, 2, 4, 2, false, true>("H0 f16 128x128, 8 x (64x32), 2 stages, 2 WG/CU (product)", 2, src, src_bytes, out);
   run<128, 128, 2, 4, 2, true, true>("H1 H0 + reads pipelined across the barrier", 2, src, src_bytes, out);
   run<128, 128, 2, 2, 2, false, true>("H2 f16 128x128, 4 x (64x64), 2 stages, 2 WG/CU", 2, src, src_bytes, out);
