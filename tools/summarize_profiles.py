@@ -31,8 +31,14 @@ def kclass(name):
         if base == "conv_gemm_kernel":
             li = re.findall(r"Li(\d+)E", s)      # <T, BN, WM, WN, KS, ...>
             return 1 if len(li) >= 4 and li[3] == "3" else 2
+        if base == "conv_wide16_kernel":         # the float16 mode's 256 x 128 tiles: <KS, RELU, RES>
+            li = re.findall(r"Li(\d+)E", s)
+            return 1 if li and li[0] == "3" else 2
         s = base
-    if s.startswith("conv3x3_1x1_kernel"):   # block 1's fused conv2 + conv3
+    if s.startswith("conv_wide16_kernel"):
+        m = re.match(r"conv_wide16_kernel<(\d+)", s)
+        return 1 if m and m.group(1) == "3" else 2
+    if s.startswith("conv3x3_1x1"):          # block 1's fused conv2 + conv3 (float32 / pieces / float16 kernels)
         return 8
     if s.startswith("conv_gemm"):
         m = re.match(r"conv_gemm_kernel<\w+, (\d+), (\d+), (\d+), (\d+)", s)   # <T, BN, WM, WN, KS, ...>
