@@ -17,7 +17,9 @@
 // partly filled last round of tiles and the tile prologues / epilogues.
 // P5 / P6 (the pieces loop in the 256 x 128 / 64-byte-stage geometry, two workgroups per CU): 550-560, +12..29 % -- the
 // pieces loop in the product's configuration moves the same 32 KB per stage as the float16 one and sits on the same
-// ~15 TB/s L2 -> LDS stream; not built (an estimated +1.5 % end to end at 720p batch 16 for the f32s precision).
+// ~15 TB/s L2 -> LDS stream.  Built as a kernel like conv_gemm_wide16.hip and measured: 3x3 class +4.5 %, end to end
+// +1.1 % in one A/B and -0.8 % in a threshold sweep at 720p batch 16, nothing at batch 64 -- the f32s layers that are
+// not HBM-bound are too small a share.  Removed again.
 // float16 mode loop (H*): 128 x 128 tiles 495-505 whatever the wave layout (the L2 -> LDS stream, ~15 TB/s, bounds it);
 // 128 x 256 tiles, 3 stages, 1 workgroup per CU 570-610 -- but built into conv_gemm_kernel that configuration lost
 // 4.5-6 % end to end (nobody multiplies during a tile's prologue / epilogue with one workgroup per CU).
