@@ -46,7 +46,10 @@
 // loop.  Built into this kernel (BN = 256, plain tiles) it LOST 4.5 % end to end at 720p and 6 % at 4K (3x3 class 2.72
 // vs 2.54 ms): with a single workgroup per CU nobody multiplies while a tile's prologue, first-stage wait and 133 KB
 // transpose run.  Removed again; what keeps two workgroups per CU at the same bytes per product is a 256 x 128 tile
-// with 64-byte K stages: conv_gemm_wide16.hip, which launch_conv_gemm picks for float16 launches of >= 256 such tiles.)
+// with 64-byte K stages: conv_gemm_wide16.hip, which launch_conv_gemm picks for float16 launches of >= 256 such tiles.
+// The same geometry for EXACT float32 -- there to spread a short-K tile's prologue, first-stage wait and epilogue over
+// twice the products -- was 5-10 % slower on exactly those layers (block 2's 128 -> 512: 333 vs 318 us, block 3's
+// 256 -> 1024: 295 vs 268 us; tools/conv_bench.py) and 4 % over the 52 launches of a step.)
 //
 // Where the main loop's time goes (ablations at batch 16, 720p, plain tiles): with the LDS-DMA
 // removed the 52 launches of a step take 17.8 ms instead of 19.6, and exactly the same with the DMA
