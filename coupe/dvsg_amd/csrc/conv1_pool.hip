@@ -306,6 +306,39 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T *__restrict__ x, T
   }
 }
 
+// float16 tensors, 8 channels = 16 bytes per thread: with 4 channels a thread moves 8-byte pieces and the kernel ran
+// at 3.2 TB/s of algorithmic traffic where the float32 one reaches 5.1 (comparisons in float16 are exact: max of
+// representable values)
+__global__ __launch_bounds__(256) void maxpool_h8_kernel(const _Float16 *__restrict__ x, _Float16 *__restrict__ y, int H,
+                                                         int W, int C8, int Ho, int Wo, int pad_top, int pad_left,
+                                                         size_t total) {
+  const size_t e = (size_t)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c8 = (int)(e % C8);
+  size_t t = e / C8;
+  const int wo = (int)(t % Wo);
+  t /= Wo;
+  const int ho = (int)(t % Ho);
+  const size_t b = t / Ho;
+  halfx8 m;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) m[q] = (_Float16)(-INFINITY);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int hi = 2 * ho - pad_top + i;
+    if (hi < 0 || hi >= H) continue;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int wi = 2 * wo - pad_left + j;
+      if (wi < 0 || wi >= W) continue;
+      const halfx8 v = *reinterpret_cast<const halfx8 *>(x + (((b * H + hi) * W + wi) * C8 + c8) * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m[q] = v[q] > m[q] ? v[q] : m[q];
+    }
+  }
+  *reinterpret_cast<halfx8 *>(y + e * 8) = m;
+}
+
 // ----------------------------------------------------------------------------------------
 // conv1 for the float16 precision: same decomposition (one output row x 128 pixels x 64 channels
 // per workgroup, the input row segment staged once per kernel row and read in place as
@@ -686,7 +719,11 @@ int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C,
   ProfScope prof(kClsMaxpool, s, 0.0, (double)elem_size(prec) * C * ((double)B * H * W + (double)B * Ho * Wo));
   if (prec == kF32S)
     hipLaunchKernelGGL(maxpool_p_kernel, dim3(blocks), dim3(256), 0, s, x, y, H, W, C / 4, Ho, Wo, pad_top, pad_left, total);
-  else if (prec == kF16)
+  else if (prec == kF16 && C % 8 == 0) {
+    const size_t total8 = total / 2;
+    hipLaunchKernelGGL(maxpool_h8_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, static_cast<const _Float16 *>(x),
+                       static_cast<_Float16 *>(y), H, W, C / 8, Ho, Wo, pad_top, pad_left, total8);
+  } else if (prec == kF16)
     hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16 *>(x),
                        static_cast<_Float16 *>(y), H, W, C / 4, Ho, Wo, pad_top, pad_left, total);
   else
