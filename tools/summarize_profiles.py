@@ -25,9 +25,9 @@ def short(n):
 
 def kclass(name):
     s = short(name)
-    m = re.search(r"_GLOBAL__N_1\d+(\w+?)I", s)   # rocprofv3 leaves _Float16 instantiations mangled
+    m = re.search(r"_GLOBAL__N_1(\d+)", s)   # rocprofv3 leaves names with _Float16 in them mangled: <length><name>
     if s.startswith("_ZN") and m:
-        base = m.group(1)
+        base = s[m.end():m.end() + int(m.group(1))]
         if base == "conv_gemm_kernel":
             li = re.findall(r"Li(\d+)E", s)      # <T, BN, WM, WN, KS, ...>
             return 1 if len(li) >= 4 and li[3] == "3" else 2
