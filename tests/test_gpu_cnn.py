@@ -295,6 +295,10 @@ def test_tile_count_regimes(net, synthetic_weights, B, H, W):
     F = net.forward(x).cpu().numpy()
     F_ref = TorchLocNet(synthetic_weights).forward(x)
     assert np.abs(F - F_ref).max() <= 1e-5
+    # the other precisions pick their own decompositions at these sizes (f32s: fat tiles; float16: 256 x 128 tiles for the
+    # launches of >= 256 of them, the fused block-1 kernel): same oracle, their own bounds
+    assert np.abs(net.forward(x, precision="f32s").cpu().numpy() - F_ref).max() <= 1e-5
+    assert np.abs(net.forward(x, precision="f16").cpu().numpy() - F_ref).max() <= 5e-5
 
 
 def test_bad_calls_are_rejected(net):
