@@ -391,7 +391,8 @@ def main():
             achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS}
-        traffic, traffic_src = pmc_traffic(cls, B, H, W, args.precision)
+        # the profiled unit is one dvsg_stabilize call: CB windows (= B at one GPU, 16 of a rank's 64 at N > 1)
+        traffic, traffic_src = pmc_traffic(cls, CB, H, W, args.precision)
         roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "kernel": KERNEL_CLASSES[cls], "launches": launches,
                          "avg_launch_ms": total_ms / max(launches, 1),

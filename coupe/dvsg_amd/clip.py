@@ -32,7 +32,8 @@ def shard_range(n, world, rank):
 def sharded_map(n, batch, produce, frame_shape, like, group=None, dst=0):
     """Run `produce(b0, b1) -> [b1-b0, *frame_shape]` over this rank's contiguous share of `n`
     independent units in batches of at most `batch`, then gather the results, in unit order, on
-    rank `dst` (None elsewhere).  No collective on the data path; one gather at the end."""
+    rank `dst` (None elsewhere).  No collective on the data path; one exchange at the end, which every rank of
+    the group must reach (ranks whose shard is empty included: they join its opening all-reduce and send nothing)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -49,6 +50,17 @@ def sharded_map(n, batch, produce, frame_shape, like, group=None, dst=0):
     # common shard size, no copy after the receive.
     on_host = local.is_cuda and dist.get_backend(group) != "nccl"
     back = local.device
+    # EVERY rank enters one cheap collective first, whatever it owns.  A rank with an empty shard (n < world,
+    # e.g. a 2-window clip on 8 GPUs) takes no part in the point-to-point exchange below, and on NCCL / RCCL a
+    # `batch_isend_irecv` that is the FIRST communication of a group must be entered by all of its ranks (it
+    # creates the communicator; otherwise the behaviour is undefined and can hang).  The all-reduce creates the
+    # communicator with everybody present and doubles as a consistency check of the sharding: the shard sizes
+    # the ranks computed must add up to n.
+    count = torch.tensor([local.shape[0]], dtype=torch.int64, device="cpu" if (on_host or not local.is_cuda) else back)
+    dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
+    if int(count.item()) != n:
+        raise RuntimeError("sharded_map: the ranks hold %d units in total, expected %d (every rank must pass the "
+                           "same n)" % (int(count.item()), n))
     if on_host:
         local = local.cpu()   # rehearsal backends (gloo) exchange through host memory; RCCL stays on the device
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)

@@ -52,7 +52,9 @@ struct Frag<_Float16> {
 // NHWC tensor whose channel count is a multiple of 32 lives in 128-byte group e / 32 -- 32 hi halves, then 32
 // lo halves -- exactly the layout of a weight row stage, so a conv GEMM's LDS-DMA moves such rows as it moves
 // float32 ones and a fragment is two ds_read_b128 with no arithmetic.  hi = f16(v), lo = f16(v - hi): hi + lo
-// is exact in float32 and carries 22 significant bits of v.
+// is exact in float32 and carries 22 significant bits of v while lo is a normal float16 (|v| >= 2^-3); below that lo
+// is a float16 subnormal with an absolute step of 2^-24 (about 20 bits at |v| = 0.03, 15 at 1e-3, float16's own 11
+// at 1e-4).  The matrix cores keep subnormal inputs, which makes the small pieces usable, not finer.
 __device__ __forceinline__ float4 load4_p(const void *base, size_t e) {
   const char *q = static_cast<const char *>(base) + (e >> 5) * 128 + (e & 31) * 2;
   const halfx4 hi = *reinterpret_cast<const halfx4 *>(q), lo = *reinterpret_cast<const halfx4 *>(q + 64);

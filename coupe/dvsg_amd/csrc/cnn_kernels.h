@@ -4,7 +4,8 @@
 // Three precisions share the kernels through template parameters:
 //   kF32   float32 activations / weights, exact-f32 matrix cores (v_mfma_f32_32x32x2_f32): the path of record
 //   kF32S  4 bytes per value and float32 accumulation, but every operand enters the float16 matrix cores as two
-//          float16 pieces (22 significant bits) and the activation tensors between layers hold those pieces;
+//          float16 pieces (22 significant bits for |x| >= 2^-3, absolute step 2^-24 below: the second piece is unscaled)
+//          and the activation tensors between layers hold those pieces;
 //          values must stay inside float16's range (|x| < 65504), which post-BatchNorm activations and BN-folded
 //          weights do by orders of magnitude
 //   kF16   float16 activations, conv weights as float16 hi / lo pairs, v_mfma_f32_32x32x16_f16 with float32
@@ -15,7 +16,7 @@
 namespace dvsg {
 
 // kF32S: 4 bytes per value and float32 accumulation like kF32, but every product is formed on the float16
-// matrix cores from two float16 pieces per operand (22 significant bits; conv_gemm.hip), and the activation
+// matrix cores from two float16 pieces per operand (22 significant bits down to |x| = 2^-3; conv_gemm.hip), and the activation
 // tensors between the layers hold those two pieces (P format, cnn_device.h) instead of one float32.
 enum Precision { kF32 = 0, kF16 = 1, kF32S = 2 };
 inline size_t elem_size(int prec) { return prec == kF16 ? 2 : 4; }

@@ -673,7 +673,10 @@ int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1
   const dim3 grid((unsigned)blocks);
   // rows that start on 16-byte boundaries: the kernels' staged segment then consists of whole aligned groups
   const bool aligned = W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-  if (out_prec == kF32S && wt1s && g_conv1_variant != 2) {
+  // the f32s activations are float16 pieces (P format): only conv1_split_kernel writes them, whatever the A/B switch says
+  // (the float32 kernel's output would be read back as pieces: silent garbage)
+  if (out_prec == kF32S && !wt1s) return fail(DVSG_ERR_UNSUPPORTED, "conv1: the f32s precision needs the piece weights");
+  if (out_prec == kF32S) {
     if (aligned)
       hipLaunchKernelGGL((conv1_split_kernel<float, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
                          bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);

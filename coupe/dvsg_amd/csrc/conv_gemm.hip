@@ -113,7 +113,7 @@ struct ConvGemmDev {
 //
 // SPLIT, T = float ("f32s" precision): float32 storage everywhere, float32 accumulation, but every
 // PRODUCT is formed on the float16 matrix cores from two float16 pieces per operand, x ~ x1 + x2 with
-// x1 = rtz_f16(x), x2 = f16(x - x1): 22 significant bits.  a w ~ a1 w1 + a2 w1 + a1 w2 (the dropped a2 w2
+// x1 = rtz_f16(x), x2 = f16(x - x1): 22 significant bits for |x| >= 2^-3 (x2 unscaled: absolute step 2^-24 below).  a w ~ a1 w1 + a2 w1 + a1 w2 (the dropped a2 w2
 // is 2^-22 relative), each float16 product exact in float32 -- three v_mfma_f32_32x32x16_f16 (96 cycles)
 // where the exact path issues eight v_mfma_f32_32x32x2_f32 (512 cycles).  Activations are split in
 // once by their producer (an epilogue stores the two pieces of each value: cnn_device.h, P format), weights

@@ -64,7 +64,8 @@ class StabNet:
         self.stabNet_model = 'resnet_v1_50'
         self.n_streams = 1   # 2 = batch halves on two HIP streams (LocNet.stabilize): <1 % at B=16 720p
         # "f32": exact float32 matrix cores (the reference's arithmetic, the path of record); "f32s": float32 width and
-        # accumulation, products from two float16 pieces per operand (2x faster, float32-GEMM-level differences);
+        # accumulation, products from two float16 pieces per operand (2x faster; float32-GEMM-level differences while operand
+        # magnitudes stay above ~2^-3 .. 0.03, fewer bits below: include/dvsg_amd.h);
         # "f16": float16 activations, hi / lo float16 conv weights
         self.precision = "f32"
         self.locnet = None

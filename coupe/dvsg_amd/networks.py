@@ -29,7 +29,7 @@ def scale_RGB(rgb):
 def _entry(base, precision):
     """C entry point for a precision: "f32" (exact float32 matrix cores, the reference's arithmetic),
     "f32s" (float32 storage and accumulation, products from two float16 pieces per operand: 22 significant
-    bits, float32-GEMM-level differences) or "f16" (float16 activations, hi / lo float16 weight pairs)."""
+    bits for |x| >= 2^-3, an absolute step of 2^-24 below -- include/dvsg_amd.h) or "f16" (float16 activations, hi / lo float16 weight pairs)."""
     if precision not in ("f32", "f32s", "f16"):
         raise ValueError("precision must be 'f32', 'f32s' or 'f16', got %r" % (precision,))
     return "%s_%s" % (base, precision)

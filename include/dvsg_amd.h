@@ -196,16 +196,23 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
                        void *workspace, size_t workspace_bytes, void *stream);
 /* ---------------------------------------------------------------------------------------
  * "f32s": float32 storage, float32 accumulation, float32-equivalent PRODUCTS from the float16 matrix
- * cores.  Same tensors, same workspace, same launch sequence as the *_f32 entry points (conv1, the max
- * dense head, the TPS solve and the warp are the float32 kernels themselves); in conv1 and the 52 1x1 / 3x3
+ * cores.  Same tensors, same workspace, same launch sequence as the *_f32 entry points (the dense head, the
+ * TPS solve and the warp are the float32 kernels themselves; the max and average pools join the two pieces of
+ * a value, which is exact); in conv1 (conv1_split_kernel) and the 52 1x1 / 3x3
  * convolutions every operand enters the matrix cores as two float16 pieces, x ~ f16(x) + f16(x - f16(x))
- * (22 significant bits), and a product is three v_mfma_f32_32x32x16_f16 -- a1 w1 + a2 w1 + a1 w2, each
+ * (22 significant bits while |x| >= 2^-3;
+ * the second piece is NOT scaled, so below that it falls into float16's subnormal range -- absolute step 2^-24 --
+ * and the pair carries about log2(|x|) + 25 bits: 20 at |x| = 0.03, 15 at 1e-3, plain float16's 11 at 1e-4), and a product is three
+ * v_mfma_f32_32x32x16_f16 -- a1 w1 + a2 w1 + a1 w2, each
  * exact in float32 -- instead of eight v_mfma_f32_32x32x2_f32.  The activation tensors between the layers
  * (library workspace) hold the two pieces of each value instead of one float32, so they are split once,
  * by the layer that produces them.  Measured against the
  * exact path: stage activations within 2e-6 relative, F_t within 1e-7, i.e. what two float32 GEMMs with
  * different summation orders differ by; every float32 parity test of tests/ also passes in this mode
- * (tests/test_gpu_f32s.py).  It is NOT the exact float32 arithmetic of the reference and is therefore a
+ * (tests/test_gpu_f32s.py) -- with operands of magnitude 0.03 .. 1 (the synthetic checkpoint, band-limited frames);
+ * a checkpoint whose BatchNorm-folded weights or activations are much smaller loses bits as stated above
+ * (tests/test_gpu_f32s.py::test_small_operands_lose_bits_as_documented) and is unpinned in this mode.
+ * It is NOT the exact float32 arithmetic of the reference and is therefore a
  * separately named precision; dvsg_*_f32 stays the path of record.  Values must stay inside float16's range
  * (|x| < 65504; beyond it a piece is infinite), which BatchNorm-folded weights and post-BatchNorm activations
  * do by orders of magnitude.

@@ -60,11 +60,12 @@ def random_mask(patches, out_size, sample_num, H):
     return (patches * mask).astype(F32), mask.astype(F32)                        # :167
 
 
-def eval_clip(weights, frames, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32)):
+def eval_clip(weights, frames, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32), grids=None):
     """eval.py:93-124 on an in-memory clip ``frames`` [N,h,w,3] float (already RGB, /255,
     resized: eval.py:76-81 is cv2 I/O and out of scope).
 
-    Returns (stabilised [N,h,w,3] float32, side_by_side uint8 [N,h,2w,3]).
+    Returns (stabilised [N,h,w,3] float32, side_by_side uint8 [N,h,2w,3]).  A list passed as `grids`
+    receives each step's source grid (x_offset_t, y_offset_t) -- the tests mask sampler A's border jumps with it.
     """
     skip_length = np.array(skip_length)
     span = int(skip_length[-1] - skip_length[0])
@@ -78,7 +79,11 @@ def eval_clip(weights, frames, h, w, skip_length=(0, 16, 24, 28, 30, 31, 32)):
     for frame_idx in range(span, len(total)):                        # :101
         batch = total[sample_idx]                                    # :103
         batch = np.expand_dims(np.concatenate(batch, axis=2), 0)     # :104
-        s_t_pred = np.squeeze(net.run(weights, batch.astype(F32), batch[:, :, :, 18:].astype(F32))[0])  # :106-110
+        s_t_pred, xs, ys = net.run(weights, batch.astype(F32), batch[:, :, :, 18:].astype(F32),
+                                   fetch=("s_t_pred", "x_offset_t", "y_offset_t"))                     # :106-110
+        s_t_pred = np.squeeze(s_t_pred)
+        if grids is not None:
+            grids.append((xs, ys))
         side = np.uint8(np.concatenate([total[sample_idx[-1]].copy(), s_t_pred], axis=1) * 255.)        # :112
         total[sample_idx[-1]] = s_t_pred                             # :116
         if frame_idx == span:                                        # :118-120

@@ -76,8 +76,11 @@ def locnet_case(weights):
 def clip_case(weights):
     c = CASES["clip"]
     frames = inputs.smooth_frames(3001, c["N"], c["H"], c["W"])
-    outs, side = omodel.eval_clip(weights, frames, c["H"], c["W"])
-    return dict(stabilised=outs, side_by_side=side)
+    grids = []
+    outs, side = omodel.eval_clip(weights, frames, c["H"], c["W"], grids=grids)
+    # per step, the pixels whose source coordinate sits within 3e-2 px of one of sampler A's jumps (packed bits)
+    mask = np.stack([otps.border_discontinuity_mask(xs, ys, c["H"], c["W"], delta=3e-2) for xs, ys in grids])
+    return dict(stabilised=outs, side_by_side=side, border_mask_bits=np.packbits(mask))
 
 
 def cfg0_case(weights):

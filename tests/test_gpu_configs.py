@@ -173,7 +173,17 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
         rF = ref.forward(x[b:b + 1].cpu().numpy())
         err = np.abs(F[b:b + 1].cpu().numpy() - rF).max()
         assert err < 1e-5, "window %d: f16 F_t error %.3g" % (b, err)
-    del out, o1
+    # window 21 in PIXELS, end to end against the float32 oracle (torch-CPU CNN -> NumPy TPS + sampler A at 4K):
+    # float16 CNN error (F_t above, x W/2 = 1920 px per unit) + the float32 evaluation noise of the map at W = 3840
+    # (tests/test_gpu_fullsize.py::test_tps_warp_4k_against_oracle) times the frames' gradient (<= 0.2 per pixel)
+    rpred, rxs, rys = otps.ThinPlateSpline(u[21:22].cpu().numpy(), inputs.v_src(1), rF, (H, W))
+    mask = otps.border_discontinuity_mask(rxs, rys, H, W, delta=5e-2).reshape(H, W)
+    perr = np.abs(out[21].cpu().numpy() - rpred[0]).max(axis=2)
+    print("cfg4 window 21: F_t error %.3g, pixels max %.3g median %.3g outside %d border pixels"
+          % (err, perr[~mask].max(), np.median(perr), int(mask.sum())))
+    assert perr[~mask].max() < 3e-3, "window 21: pixel error %.3g" % perr[~mask].max()
+    assert mask.mean() < 0.005
+    del out, o1, rpred, perr
     # the warp stage of configs[4] (float32 in both modes) at 4K: zero control vectors -> identity grid
     coord = torch.from_numpy(inputs.v_src(2)).to(dev)
     o, xg, yg = ThinPlateSpline(u[:2], coord, torch.zeros_like(coord), (H, W))

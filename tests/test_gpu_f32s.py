@@ -1,6 +1,6 @@
 """GPU: the "f32s" precision -- float32 storage and accumulation, every product of the 52 1x1 / 3x3
 convolutions formed on the float16 matrix cores from two float16 pieces per operand (22 significant
-bits; include/dvsg_amd.h, conv_gemm.hip).  It is held to the SAME bounds as the exact float32 path in
+bits for |x| >= 2^-3, an absolute step of 2^-24 below; include/dvsg_amd.h, conv_gemm.hip).  It is held to the SAME bounds as the exact float32 path in
 tests/test_gpu_cnn.py / test_gpu_configs.py: stage activations <= 2e-5 relative, F_t <= 1e-5, warped
 pixels < 1e-3 at 720p outside the counted border-discontinuity pixels -- and, against the exact path
 itself, to the level at which two float32 GEMMs with different summation orders differ."""
@@ -164,7 +164,7 @@ def test_clip_loop_and_determinism(synthetic_weights):
     from coupe.dvsg_amd.model import Session, StabNet
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip.npz")
     with np.load(gold, allow_pickle=False) as z:
-        ref = z["stabilised"]
+        ref, bits = z["stabilised"], z["border_mask_bits"]
     N, H, W = 40, 32, 48
     frames = inputs.smooth_frames(3001, N, H, W)
     model = StabNet(H, W).load_weights(synthetic_weights)
@@ -172,5 +172,45 @@ def test_clip_loop_and_determinism(synthetic_weights):
     model.get_evaluation_model(7)
     out = stabilize_clip(model, Session(), frames)
     err = np.abs(out - ref).reshape(N, -1)
-    assert np.median(err, axis=1).max() < 1e-5 and (err > 1e-3).mean(axis=1).max() < 0.02
+    assert np.median(err, axis=1).max() < 3e-6 and (err > 1e-3).mean(axis=1).max() <= 1e-3
+    mask = np.unpackbits(bits)[:N * H * W].astype(bool).reshape(N, H, W)
+    assert np.abs(out - ref).max(axis=3)[~mask].max() < 1e-4     # nothing flips away from sampler A's border jumps
     assert np.array_equal(out, stabilize_clip(model, Session(), frames))
+
+
+def test_small_operands_lose_bits_as_documented():
+    """The second piece is stored UNSCALED (lo = f16(v - hi)), so for |v| < 2^-3 it is a float16 subnormal with an
+    absolute step of 2^-24: the pair carries ~20 bits at |v| = 0.03, ~15 at 1e-3 (include/dvsg_amd.h).  The parity
+    tests above run on weights of ~0.03 .. 0.1; this one states what the mode gives with BatchNorm-folded weights of
+    magnitude ~1e-3 against O(1) activations, measured against float64 math on the TRUE float32 operands (CPU
+    emulation of the same arithmetic: 3.0e-5 of the output scale; weights of 0.06: 5e-7; plain float16 operands:
+    3e-4; exact float32: 1e-7).  Better than float16 by 10x, short of float32 by 100x: a checkpoint with such
+    magnitudes is unpinned in this mode."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    stream = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+    Bs, h, w, cin, cout, k = 2, 20, 28, 256, 128, 1
+    x = (torch.rand((Bs, h, w, cin), generator=g, device=dev) - 0.25) * 2.0
+    wt = (torch.rand((cout, cin), generator=g, device=dev) - 0.5) * 2e-3
+    bias = torch.zeros((cout,), device=dev)
+    xp = _to_pieces(x)
+    hi = wt.half()
+    lo = (wt - hi.float()).half()
+    pieces = torch.cat([hi.reshape(cout, cin // 32, 32), lo.reshape(cout, cin // 32, 32)], 2).contiguous()
+    yp = torch.empty(Bs * h * w * cout * 4, dtype=torch.uint8, device=dev)
+    y32 = torch.empty((Bs, h, w, cout), device=dev)
+    _lib.call("dvsg_conv_gemm_f32s", xp.data_ptr(), pieces.data_ptr(), bias.data_ptr(), 0, yp.data_ptr(), Bs, h, w, cin, cout,
+              k, 1, 0, 1, scratch.data_ptr(), scratch.numel(), stream)
+    _lib.call("dvsg_conv_gemm_f32", x.data_ptr(), wt.data_ptr(), bias.data_ptr(), 0, y32.data_ptr(), Bs, h, w, cin, cout,
+              k, 1, 0, 1, scratch.data_ptr(), scratch.numel(), stream)
+    ref = x.double().reshape(-1, cin) @ wt.double().t()
+    ys = _from_pieces(yp, y32.shape).double().reshape(-1, cout)
+    scale = float(ref.abs().max())
+    es, e32 = float((ys - ref).abs().max()) / scale, float((y32.double().reshape(-1, cout) - ref).abs().max()) / scale
+    e16 = float(((x.half().double().reshape(-1, cin) @ wt.half().double().t()) - ref).abs().max()) / scale
+    print("weights ~1e-3: relative error f32s %.2e, exact float32 %.2e, plain float16 operands %.2e" % (es, e32, e16))
+    assert e32 < 1e-6
+    assert es < 1e-4 and es < e16     # bounded and stated: NOT float32-level here

@@ -141,3 +141,40 @@ def test_stream_split_is_invisible(dev, synthetic_weights):
         for a, b in zip(res[0][1:], other[1:]):
             assert float((a - b).abs().max()) <= 1e-6
         assert float(((res[0][0] - other[0]).abs() > 1e-4).float().mean()) < 1e-3
+
+
+def test_tps_warp_4k_against_oracle(dev):
+    """One 3840x2160 frame through `dvsg_tps_warp_f32` with NON-zero control vectors against the NumPy oracle
+    (ThinPlateSpline.py:92-141; the 4K tests so far checked the identity map only).  Given the oracle's own T, so
+    that what is measured is the float32 evaluation of the 28-term map and sampler A at W = 3840: two correct
+    float32 evaluations differ by a few 1e-6 in normalised coordinates, i.e. by ~1e-2 px here (SURVEY.md section 7,
+    hard part 2, predicts ~7e-3), and a warped value by that times the local image gradient.  The frame is
+    band-limited noise at 1/16 resolution (|dI/dx| <= 0.1 per pixel)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    from oracle import thin_plate_spline as otps
+    h, w, C = 2160, 3840, 3
+    U = inputs.smooth_frames(61, 1, h, w, C, factor=16)
+    coord = inputs.v_src(1)
+    vec = inputs.control_vectors(62, 1)
+    T = otps.solve_system(coord, (coord + vec).astype(np.float32))
+    xo, yo = otps.source_coords(T, coord, h, w)
+    ref = otps.interpolate_a(U, xo, yo).reshape(1, h, w, C)
+    tU, tc, tT = (torch.from_numpy(a).to(dev) for a in (U, coord, T))
+    out = torch.empty((1, h, w, C), device=dev)
+    xs = torch.empty((h * w,), device=dev)
+    ys = torch.empty((h * w,), device=dev)
+    _lib.call("dvsg_tps_warp_f32", tU.data_ptr(), tc.data_ptr(), tT.data_ptr(), 1, h, w, C, 25, h, w,
+              out.data_ptr(), xs.data_ptr(), ys.data_ptr(), 0)
+    torch.cuda.synchronize()
+    ex = np.abs(xs.cpu().numpy() - xo[0]) * w / 2
+    ey = np.abs(ys.cpu().numpy() - yo[0]) * h / 2
+    mask = otps.border_discontinuity_mask(xo, yo, h, w, delta=5e-2).reshape(h, w)
+    err = np.abs(out.cpu().numpy()[0] - ref[0]).max(axis=2)
+    print("4K TPS warp vs oracle: grid error %.3g px (x) %.3g px (y); pixels max %.3g, median %.3g outside %d border pixels "
+          "(%.4f%% of the frame)" % (ex.max(), ey.max(), err[~mask].max(), np.median(err), int(mask.sum()), 100 * mask.mean()))
+    assert max(ex.max(), ey.max()) < 3e-2, "grid error %.3g px" % max(ex.max(), ey.max())
+    assert err[~mask].max() < 2e-3, "pixel error %.3g" % err[~mask].max()
+    # a warped value may move by the coordinate error times the gradient and no more
+    assert (err - 0.25 * (ex + ey).reshape(h, w))[~mask].max() < 2e-5
+    assert mask.mean() < 0.005

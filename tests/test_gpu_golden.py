@@ -69,8 +69,14 @@ def test_eval_clip_loop(synthetic_weights):
     med, mx, bad = np.median(err, axis=1), err.max(axis=1), (err > 1e-3).mean(axis=1)
     print("clip N=40 per-step error: median max %.2e (step %d), max %.2e (step %d), pixels > 1e-3: max %.3f%%"
           % (med.max(), med.argmax(), mx.max(), mx.argmax(), 100 * bad.max()))
-    assert med.max() < 1e-5, "median error per step %s" % med
-    assert bad.max() < 0.02, "fraction of pixels off by > 1e-3, per step: %s" % bad
+    # measured (round 2, MI355X): median 8.9e-7, max 1.3e-5, no value off by more than 1e-3 at any step; bounds ~3x that
+    assert med.max() < 3e-6, "median error per step %s" % med
+    assert bad.max() <= 1e-3, "fraction of values off by > 1e-3, per step: %s" % bad
+    # away from sampler A's border jumps (the oracle's own per-step mask, delta 3e-2 px) nothing may flip at all
+    mask = np.unpackbits(g["border_mask_bits"])[:N * H * W].astype(bool).reshape(N, H, W)
+    inner = np.abs(out - ref).max(axis=3)[~mask]
+    assert inner.max() < 1e-4, "max error away from the border jumps %.3g" % inner.max()
+    assert mask.mean(axis=(1, 2)).max() < 0.05
     assert np.array_equal(side[:, :, :W], rside[:, :, :W])      # left half: the unstable input
     diff = np.abs(side[:, :, W:].astype(int) - rside[:, :, W:].astype(int))
     assert (diff > 1).mean() < 0.01

@@ -306,3 +306,76 @@ def test_argument_errors(dev):
         _lib.call("dvsg_tps_solve_f32", 8, 8, 1, 1, 2, 8, 0)
     with pytest.raises(DvsgError, match="NULL"):
         _lib.call("dvsg_flow_warp_f32", 0, 0, 1, 4, 4, 3, 0, 0)
+
+
+# ------------------------------------------------- sampler A far outside the frame, at scale
+def _sampler_a_noise_bound(xo, yo, H, W):
+    """Rounding noise of sampler A's four-term sum (ThinPlateSpline.py:81-89) per unit of intensity.  The
+    weights come from the CLIPPED tap indices (:57-60), so a source coordinate d px outside the frame gives
+    coincident taps with weights of size ~d that cancel only up to rounding: |noise| <~ ulp(wx wy).  Inside
+    the frame the weights are <= 1 and this is ~1e-7."""
+    x = (np.asarray(xo, np.float64) + 1.0) * W / 2.0
+    y = (np.asarray(yo, np.float64) + 1.0) * H / 2.0
+    wx = np.maximum(np.abs(np.clip(np.floor(x) + 1, 0, W - 1) - x), np.abs(x - np.clip(np.floor(x), 0, W - 1)))
+    wy = np.maximum(np.abs(np.clip(np.floor(y) + 1, 0, H - 1) - y), np.abs(y - np.clip(np.floor(y), 0, H - 1)))
+    return 8.0 * 2.0 ** -23 * np.maximum(wx, 1.0) * np.maximum(wy, 1.0)
+
+
+@pytest.mark.parametrize("frames", ["smooth", "white_noise"])
+def test_tps_large_displacement_out_of_frame(dev, frames):
+    """Control vectors of scale 0.5 plus a uniform shift of 1.5 (normalised units: three quarters of the frame):
+    a large part of every output frame samples OUTSIDE the image, where sampler A clips the tap indices first and
+    takes the weights from the clipped integers (ThinPlateSpline.py:57-60, 81-88) -- the taps coincide and the
+    weights cancel to ~0 instead of fading out.  Until now that cancellation was only exercised on the last
+    row / column.  Checked with the oracle's T fed through the C ABI (isolates grid + sampler) and end to end
+    through the facade against the float64-solved system (the oracle's float32 LU noise grows with |rhs|)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    from coupe.dvsg_amd.ThinPlateSpline import ThinPlateSpline
+    B, H, W, C = 2, 72, 128, 3
+    if frames == "smooth":
+        U = inputs.smooth_frames(71, B, H, W, C)
+    else:
+        U = np.random.default_rng(72).uniform(0.0, 1.0, (B, H, W, C)).astype(np.float32)
+    coord = inputs.v_src(B)
+    vec = inputs.control_vectors(73, B, scale=0.5)
+    vec[0, :, 0] += 1.5            # sample 0 shifted in x, sample 1 in y (and the other way in x)
+    vec[1, :, 1] += 1.5
+    vec[1, :, 0] -= 0.75
+    T = otps.solve_system(coord, (coord + vec).astype(np.float32), dtype=np.float64).astype(np.float32)
+    xo, yo = otps.source_coords(T, coord, H, W)
+    ref = otps.interpolate_a(U, xo, yo).reshape(B, H, W, C)
+    xp, yp = (xo.astype(np.float64) + 1) * W / 2, (yo.astype(np.float64) + 1) * H / 2
+    outside = ((xp < -1) | (xp > W) | (yp < -1) | (yp > H)).reshape(B, H, W)
+    assert 0.3 < outside.mean() < 0.95, "the case must put a large part of the frame outside: %.2f" % outside.mean()
+    noise = _sampler_a_noise_bound(xo, yo, H, W).reshape(B, H, W)
+    # the oracle's own output out there is the cancellation residue, not an image value
+    assert (np.abs(ref).max(axis=3)[outside] <= noise[outside]).all()
+    tU, tc, tT = (torch.from_numpy(a).to(dev) for a in (U, coord, T))
+    out = torch.empty((B, H, W, C), device=dev)
+    xs = torch.empty((B * H * W,), device=dev)
+    ys = torch.empty((B * H * W,), device=dev)
+    _lib.call("dvsg_tps_warp_f32", tU.data_ptr(), tc.data_ptr(), tT.data_ptr(), B, H, W, C, 25, H, W,
+              out.data_ptr(), xs.data_ptr(), ys.data_ptr(), 0)
+    torch.cuda.synchronize()
+    xs, ys, out = xs.cpu().numpy().reshape(B, -1), ys.cpu().numpy().reshape(B, -1), out.cpu().numpy()
+    ex = np.abs(xs - xo).reshape(B, H, W) * W / 2
+    ey = np.abs(ys - yo).reshape(B, H, W) * H / 2
+    print("large displacement (%s): outside %.0f%%, grid error %.3g px, |T| max %.3g" % (frames, 100 * outside.mean(), max(ex.max(), ey.max()), np.abs(T).max()))
+    assert max(ex.max(), ey.max()) < 2e-2           # |T| is ~10x the small-vector cases': float32 evaluation noise scales with it
+    mask = otps.border_discontinuity_mask(xo, yo, H, W, delta=3e-2).reshape(B, H, W)
+    err = np.abs(out - ref).max(axis=3)
+    assert (np.abs(out).max(axis=3)[outside] <= noise[outside]).all(), "outside the frame the taps must cancel"
+    # inside: a warped value moves by at most the coordinate error times the image gradient (<= 1 per px)
+    slack = err - 2.0 * (ex + ey) - 2.0 * noise
+    assert slack[~mask].max() <= 2e-5, "worst excess %.3g" % slack[~mask].max()
+    if frames == "smooth":
+        assert err[~mask & ~outside].max() < 3e-3
+    # end to end (GPU float64 solve -> T -> grid -> sampler): same frames, same bounds
+    o2, x2, y2 = ThinPlateSpline(U, coord, vec, (H, W))
+    ex2 = np.abs(x2.reshape(B, H, W) - xo.reshape(B, H, W)) * W / 2
+    ey2 = np.abs(y2.reshape(B, H, W) - yo.reshape(B, H, W)) * H / 2
+    assert max(ex2.max(), ey2.max()) < 3e-2
+    err2 = np.abs(o2 - ref).max(axis=3)
+    assert (err2 - 2.0 * (ex2 + ey2) - 2.0 * noise)[~mask].max() <= 2e-5
+    assert (np.abs(o2).max(axis=3)[outside & ~mask] <= noise[outside & ~mask]).all()

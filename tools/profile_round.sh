@@ -11,7 +11,8 @@ OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 rm -rf "$OUT"
 mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+# --no-secondary: the f32s leg bench.py reports beside the f32 line must not be in the profile (round 2 mixed them)
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \

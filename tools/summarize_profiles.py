@@ -49,6 +49,35 @@ def kclass(name):
     return None
 
 
+def kprec(name):
+    """Precision a kernel symbol belongs to: "f32" (exact float32 matrix cores), "f32s" (float32 from two float16
+    pieces: SPLIT conv_gemm with T = float, conv1_split_kernel, the *_p_kernel family, conv3x3_1x1_kernel<*, true>),
+    "f16" (float16 activations), or None for the kernels every mode shares (head, TPS, samplers, tickets).  A traffic
+    file holds ONE precision: round 2's mixed the f32 launches with the f32s launches of bench.py's `secondary` leg."""
+    s = short(name)
+    if s.startswith("_ZN"):
+        m = re.search(r"_GLOBAL__N_1(\d+)", s)
+        base = s[m.end():m.end() + int(m.group(1))] if m else s
+        if base == "conv1_split_kernel":
+            return "f32s"
+        if base == "conv_gemm_kernel":
+            return "f16" if "IDF16_" in s else ("f32s" if s.split("EEv")[0].endswith("Lb1") else "f32")
+        return "f16" if "DF16_" in s else None
+    if s.startswith(("conv_wide16_kernel", "conv3x3_1x1_f16_kernel", "conv1_f16_kernel", "maxpool_h8_kernel")) or "_Float16" in s:
+        return "f16"
+    if s.startswith(("conv1_split_kernel", "maxpool_p_kernel", "avgpool_partial_p_kernel")):
+        return "f32s"
+    m = re.match(r"conv3x3_1x1_kernel<\d+, (true|false)>", s)
+    if m:
+        return "f32s" if m.group(1) == "true" else "f32"
+    m = re.match(r"conv_gemm_kernel<float(?:, \w+)*, (true|false)>", s)
+    if m:
+        return "f32s" if m.group(1) == "true" else "f32"
+    if s.startswith(("conv1_kernel", "maxpool_kernel<float>", "avgpool_partial_kernel<float>")):
+        return "f32"
+    return None
+
+
 def newest(pattern):
     """gpurun merges every call's files into the same directory: take the latest run's."""
     return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
@@ -67,8 +96,12 @@ def counters(d):
     return per, disp, dur
 
 
-def write_pmc(d, path):
+def write_pmc(d, path, precision):
     per, disp, dur = counters(d)
+    foreign = sorted({short(k) for k in per if kclass(k) is not None and kprec(k) not in (None, precision)})
+    if foreign:
+        raise SystemExit("%s: launches of another precision than %s in this pass (profile with --no-secondary): %s"
+                         % (d, precision, foreign[:4]))
     names = sorted({c for k in per for c in per[k]})
     with open(path, "w", newline="") as f:
         w = csv.writer(f)
@@ -92,9 +125,10 @@ def workload_of(flags):
 def main(src, dst, tag, flags=""):
     stats = newest(src + "/stats/**/*_kernel_stats.csv")
     shutil.copy(stats, "%s/%s_kernel_stats.csv" % (dst, tag))
-    write_pmc(src + "/pmc_sq", "%s/%s_pmc_sq.csv" % (dst, tag))
-    fetch, fdisp = write_pmc(src + "/pmc_fetch", "%s/%s_pmc_fetch.csv" % (dst, tag))
-    write, wdisp = write_pmc(src + "/pmc_write", "%s/%s_pmc_write.csv" % (dst, tag))
+    prec = workload_of(flags)["precision"]
+    write_pmc(src + "/pmc_sq", "%s/%s_pmc_sq.csv" % (dst, tag), prec)
+    fetch, fdisp = write_pmc(src + "/pmc_fetch", "%s/%s_pmc_fetch.csv" % (dst, tag), prec)
+    write, wdisp = write_pmc(src + "/pmc_write", "%s/%s_pmc_write.csv" % (dst, tag), prec)
     traffic = {}
     for cls in range(9):
         fb = sum(fetch[k]["FETCH_SIZE"] for k in fetch if kclass(k) == cls) * 1024.0 * 2.0
@@ -106,7 +140,8 @@ def main(src, dst, tag, flags=""):
                                  "bytes_per_launch": fb / fn + wb / wn, "launches_profiled": fn}
     json.dump({"note": "FETCH_SIZE x1024 x2 (gfx950 half-count correction) + WRITE_SIZE x1024, separate --pmc passes; "
                        "memory-side (fabric) requests, Infinity-Cache hits included",
-               "workload": workload_of(flags), "classes": traffic},
+               "workload": workload_of(flags), "precision_checked": "every profiled conv / pool launch is a %s kernel" % prec,
+               "classes": traffic},
               open("%s/%s_traffic.json" % (dst, tag), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
