@@ -48,14 +48,21 @@ constexpr int C1_LDC = 68;                                    // epilogue tile r
 // ----------------------------------------------------------------------------------------
 template <int NT, int GROUPS, bool ALIGNED>
 struct Conv1Row {
+  static constexpr bool kRing = false;
   typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
   float mean[4 * GROUPS];
   long idx[GROUPS];
   unsigned col_ok, full;
   floatx4 reg[GROUPS];   // the row in flight (prefetched under the previous kernel row's MFMAs)
   bool row_ok;
+  const float *img;      // window b
+  long row_elems;
+  int H;
 
-  __device__ __forceinline__ void init(int tid, int wo0, long row_elems, int seg_elems) {
+  __device__ __forceinline__ void init(const Conv1Src &src, int tid, int b, int wo0, int H_, int W, int seg_elems) {
+    H = H_;
+    row_elems = (long)W * kConv1Cin;
+    img = static_cast<const float *>(src.base) + (long)b * H * row_elems;
     const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
     col_ok = full = 0;
     row_ok = false;
@@ -76,12 +83,12 @@ struct Conv1Row {
       idx[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;   // ALIGNED: a group outside the row reads the row's first
     }
   }
-  // input row 2 ho + kh - 3 of image b (clamped into the image; `row_ok` remembers whether it was inside)
-  __device__ __forceinline__ void load(const float *x, int b, int H, long row_elems, int ho, int kh) {
+  // input row 2 ho + kh - 3 (clamped into the image; `row_ok` remembers whether it was inside)
+  __device__ __forceinline__ void load(int ho, int kh) {
     const int hi = 2 * ho + kh - 3;
     row_ok = hi >= 0 && hi < H;
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
-    const float *xrow = x + ((long)b * H + hc) * row_elems;
+    const float *xrow = img + (long)hc * row_elems;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       if constexpr (ALIGNED) {
@@ -104,14 +111,158 @@ struct Conv1Row {
   }
 };
 
+// ----------------------------------------------------------------------------------------
+// The same staged segment assembled from a FRAME RING instead of a window tensor (SURVEY.md 8f-1/-2,
+// eval.py:103-104: `np.concatenate` of the 7 window frames fused into this load stage).  The source is a pool
+// of RGB frames [n_pool][H][W][3] -- float32 in [0,1], or the raw uint8 frames, whose `/ 255.` (eval.py:80) is
+// fused here too -- and window b consists of the pool frames table[b][0..6], oldest to newest.  Element e of the
+// staged segment (pixel p = (e - 1) / 21 of the segment, channel c = 3 f + rgb) is float 3 p' + rgb of row
+// `hi` of frame f: per frame the segment is ONE contiguous run of 3 * 261 row elements, fetched in groups of
+// four from one pixel before the run (a multiple of four elements of the row, like the window path's "one
+// element before"), and each element is scattered to its place in the pixel-major LDS image.  So the LDS
+// image, the weights and the MFMA loop are the window kernels' own; only the staging differs: the same number
+// of global loads (4 elements each), ds_write_b32 / b16 per element instead of b128 per group.
+// uint8: f32(double(v) / 255.) * 255.f == (float)v EXACTLY for all 256 byte values (exhaustive:
+// tests/test_frames_cpu.py), so the scaled value float(v) - mean is bit-identical to the float path's
+// x * 255 - mean on the converted frame, with one conversion and one subtraction per element.
+// An index outside [0, n_pool) stages zeros (raw domain), like dvsg_window_gather_f32.
+// ----------------------------------------------------------------------------------------
+constexpr int C1_RING_PX = 2 * (C1_TILE - 1) + 7;            // 261 pixels of the input row feed a tile
+constexpr int C1_RING_RG = (3 * (C1_RING_PX + 1) + 3) / 4;   // 197 groups of four per frame: one pixel of lead-in + the run
+constexpr int C1_RING_GROUPS = 7 * C1_RING_RG;               // 1379
+
+template <int NT, int GROUPS, typename TS, bool ALIGNED>
+struct Conv1RingRow {
+  static constexpr bool kRing = true;
+  static constexpr bool kU8 = sizeof(TS) == 1;
+  static_assert(NT * GROUPS >= C1_RING_GROUPS, "not enough threads x groups for 7 frame runs");
+  static_assert(GROUPS <= 8, "per-element masks are 32 bits wide");
+  typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
+  float mean[4 * GROUPS];
+  long off[GROUPS];        // element offset of the group in the pool, row 0 of its frame
+  int l0[GROUPS];          // LDS element of the first value's PIXEL (channel 3 f of it)
+  unsigned phase;          // 2 bits per group: rgb of the group's first value
+  unsigned col_ok, st_ok;  // per element: inside the image row / inside the staged segment
+  floatx4 regf[kU8 ? 1 : GROUPS];
+  unsigned regu[kU8 ? GROUPS : 1];
+  bool row_ok;
+  const TS *pool;
+  long row_elems;
+  int H;
+
+  __device__ __forceinline__ void init(const Conv1Src &src, int tid, int b, int wo0, int H_, int W, int /*seg_elems*/) {
+    H = H_;
+    row_elems = (long)W * 3;
+    pool = static_cast<const TS *>(src.base);
+    const long frame_elems = (long)H * row_elems;
+    const long r_first = (long)(2 * wo0 - 4) * 3;    // one pixel before the segment: a multiple of 4
+    col_ok = st_ok = phase = 0;
+    row_ok = false;
+#pragma unroll
+    for (int i = 0; i < GROUPS; ++i) {
+      const int q = tid + NT * i;
+      const int f = q / C1_RING_RG, g = q - f * C1_RING_RG;
+      const bool in_range = q < C1_RING_GROUPS;
+      const int fi = in_range ? src.table[b * 7 + f] : -1;
+      const bool frame_ok = fi >= 0 && fi < src.n_pool;
+      const long r0 = r_first + 4 * g;
+      unsigned mc = 0, ms = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = 4 * g + j;                      // element of the run, lead-in pixel included
+        const int c = 3 * f + t % 3;
+        const int grp = c / (kConv1Cin / 3);
+        mean[4 * i + j] = grp == 0 ? 123.68f : (grp == 1 ? 116.779f : 103.939f);
+        if (in_range && t >= 3 && t < 3 * (C1_RING_PX + 1)) ms |= 1u << j;
+        if (frame_ok && r0 + j >= 0 && r0 + j < row_elems) mc |= 1u << j;
+      }
+      // ALIGNED: a group lies inside the row or outside it as a whole (both ends of the row and the run's start are
+      // multiples of four elements); outside -- or with a frame index outside the pool -- it reads row `hc` of the pool's
+      // first frame and its values are dropped.  Element-wise otherwise.
+      const bool whole = mc == 15u;
+      if (ALIGNED && !whole) mc = 0;
+      col_ok |= mc << (4 * i);
+      st_ok |= ms << (4 * i);
+      off[i] = (ALIGNED && !whole) ? 0 : (frame_ok ? (long)fi * frame_elems : 0) + r0;
+      // value j of the group: t = 4 g + j, pixel t / 3 of the run (the lead-in pixel is -1 of the segment), rgb t % 3,
+      // LDS element 1 + 21 (t / 3 - 1) + 3 f + t % 3
+      l0[i] = 1 + kConv1Cin * ((4 * g) / 3 - 1) + 3 * f;
+      phase |= (unsigned)((4 * g) % 3) << (2 * i);
+    }
+  }
+  __device__ __forceinline__ void load(int ho, int kh) {
+    const int hi = 2 * ho + kh - 3;
+    row_ok = hi >= 0 && hi < H;
+    const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
+    const long roff = (long)hc * row_elems;
+#pragma unroll
+    for (int i = 0; i < GROUPS; ++i) {
+      const TS *p = pool + off[i] + roff;
+      if constexpr (kU8) {
+        if constexpr (ALIGNED) {
+          regu[i] = *reinterpret_cast<const unsigned *>(p);
+        } else {
+          unsigned w = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((col_ok >> (4 * i + j)) & 1u) w |= (unsigned)p[j] << (8 * j);
+          regu[i] = w;
+        }
+      } else {
+        if constexpr (ALIGNED) {
+          regf[i] = *reinterpret_cast<const floatx4 *>(p);
+        } else if (((col_ok >> (4 * i)) & 15u) == 15u) {
+          regf[i] = *reinterpret_cast<const floatx4_u *>(p);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) regf[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? (float)p[j] : 0.f;
+        }
+      }
+    }
+  }
+  // every staged element of the row in flight, scaled: put(LDS element index, value)
+  template <typename PUT>
+  __device__ __forceinline__ void scatter(PUT put) const {
+    const unsigned ok = row_ok ? col_ok : 0u;
+#pragma unroll
+    for (int i = 0; i < GROUPS; ++i) {
+      const int ph = (phase >> (2 * i)) & 3u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float raw;
+        if constexpr (kU8) raw = (float)((regu[i] >> (8 * j)) & 255u);   // == f32(v / 255.) * 255.f, exactly
+        else raw = regf[i][j] * 255.0f;
+        const float v = ((ok >> (4 * i + j)) & 1u) ? raw - mean[4 * i + j] : 0.f;
+        const int t = ph + j, step = t / 3;                              // t in 0..5
+        if ((st_ok >> (4 * i + j)) & 1u) put(l0[i] + kConv1Cin * step + (t - 3 * step), v);
+      }
+    }
+  }
+};
+
+// SRC of the conv1 kernels: bit 0 = rows on the 16-byte (4-byte for uint8) grid; 0/1 window tensor, 2/3 float32 frame
+// ring, 4/5 uint8 frame ring.
+template <int NT, int GROUPS, int SRC>
+struct Conv1RowSel {
+  typedef Conv1Row<NT, GROUPS, (SRC & 1) != 0> type;
+};
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 2> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, float, false> type; };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 3> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, float, true> type; };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 4> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, uint8_t, false> type; };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 5> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, uint8_t, true> type; };
+
 #ifdef DVSG_STAMPS  // diagnostic build (tools/stamp_probe_conv1.py): per-workgroup phase times of conv1_kernel
 __device__ unsigned long long g_c1_stamps[8 * 65536];
 #define C1_STAMP() __builtin_amdgcn_s_memtime()
 #endif
 
-template <int NW, typename TO, bool ALIGNED>
+template <int NW, typename TO, int SRC>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
-void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, const float *__restrict__ bias,
+void conv1_kernel(const Conv1Src src, const float *__restrict__ wt1, const float *__restrict__ bias,
                   TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
   constexpr int NT = 64 * NW;
   constexpr int MI = 4 / (NW / 2);                       // 32-pixel MFMA blocks per wave: 2 or 1
@@ -134,12 +285,15 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  const long row_elems = (long)W * kConv1Cin;
-  Conv1Row<NT, IN4, ALIGNED> row;
-  row.init(tid, wo0, row_elems, C1_SEG_PAD);
+  typedef typename Conv1RowSel<NT, IN4, SRC>::type Row;
+  Row row;
+  row.init(src, tid, b, wo0, H, W, C1_SEG_PAD);
+  if constexpr (Row::kRing) {   // elements the scatter never writes (the zero tap's slot, the tail) must be finite
+    for (int e = tid; e < C1_SEG_PAD; e += NT) in_s[e] = 0.f;
+  }
   floatx4 w_reg[WLOADS];
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
-    row.load(x, b, H, row_elems, ho, kh);
+    row.load(ho, kh);
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1 + (size_t)kh * C1_WELEMS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -148,11 +302,15 @@ void conv1_kernel(const float *__restrict__ x, const float *__restrict__ wt1, co
     }
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
+    if constexpr (Row::kRing) {
+      row.scatter([&](int e, float v) __attribute__((always_inline)) { in_s[e] = v; });
+    } else {
 #pragma unroll
-    for (int i = 0; i < IN4; ++i) {
-      const int q = tid + NT * i;
-      const floatx4 v = row.scaled(i);
-      if (q < C1_SEG_PAD / 4) reinterpret_cast<floatx4 *>(in_s)[q] = v;
+      for (int i = 0; i < IN4; ++i) {
+        const int q = tid + NT * i;
+        const floatx4 v = row.scaled(i);
+        if (q < C1_SEG_PAD / 4) reinterpret_cast<floatx4 *>(in_s)[q] = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -356,9 +514,9 @@ constexpr int C1H_WBYTES = 64 * C1H_LD * 2;        // 21504 bytes per kernel row
 constexpr int C1H_SEG = 5504;                      // halfs per staged input row (5481 + zero tail)
 constexpr int C1H_IN4 = (C1H_SEG / 4 + 255) / 256;     // 6 groups of four elements per thread
 
-template <typename TO, bool ALIGNED>
+template <typename TO, int SRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1h, const float *__restrict__ bias,
+void conv1_f16_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h, const float *__restrict__ bias,
                       TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
   static_assert(C1_TILE * C1_LDC * 4 <= 2 * C1H_WBYTES, "epilogue tile must fit in the weight stages");
   __shared__ __attribute__((aligned(16))) char lds[2 * C1H_WBYTES + 2 * C1H_SEG * 2];
@@ -375,9 +533,12 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  const long row_elems = (long)W * kConv1Cin;
-  Conv1Row<256, C1H_IN4, ALIGNED> row;
-  row.init(tid, wo0, row_elems, C1H_SEG);
+  typedef typename Conv1RowSel<256, C1H_IN4, SRC>::type Row;
+  Row row;
+  row.init(src, tid, b, wo0, H, W, C1H_SEG);
+  if constexpr (Row::kRing) {   // both images: the zero tap's slot and the tail are read against zero weights
+    for (int e = tid; e < C1H_SEG; e += 256) reinterpret_cast<unsigned *>(in_s)[e] = 0u;
+  }
 
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
@@ -387,19 +548,24 @@ void conv1_f16_kernel(const float *__restrict__ x, const _Float16 *__restrict__ 
     for (int j = wave; j < C1H_WBYTES / 1024; j += 4)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024 + lane * 16), (lptr_t)(w_s + buf * C1H_WBYTES + j * 1024),
                                        16, 0, 0);
-    row.load(x, b, H, row_elems, ho, kh);
+    row.load(ho, kh);
   };
   auto store_stage = [&](int buf) __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    half4_t *dst = reinterpret_cast<half4_t *>(in_s + buf * C1H_SEG * 2);
+    if constexpr (Row::kRing) {
+      _Float16 *dsth = reinterpret_cast<_Float16 *>(in_s + buf * C1H_SEG * 2);
+      row.scatter([&](int e, float v) __attribute__((always_inline)) { dsth[e] = (_Float16)v; });
+    } else {
+      half4_t *dst = reinterpret_cast<half4_t *>(in_s + buf * C1H_SEG * 2);
 #pragma unroll
-    for (int i = 0; i < C1H_IN4; ++i) {
-      const int q = tid + 256 * i;
-      const floatx4 v = row.scaled(i);   // then one rounding to f16
-      half4_t hv;
+      for (int i = 0; i < C1H_IN4; ++i) {
+        const int q = tid + 256 * i;
+        const floatx4 v = row.scaled(i);   // then one rounding to f16
+        half4_t hv;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
-      if (q < C1H_SEG / 4) dst[q] = hv;
+        for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
+        if (q < C1H_SEG / 4) dst[q] = hv;
+      }
     }
   };
 
@@ -490,9 +656,9 @@ constexpr int C1S_IN4 = (C1S_SEG / 4 + 255) / 256;     // 6 groups of four eleme
 constexpr int C1S_WHALFS = 2 * 64 * kConv1LdH;       // halves per kernel row: hi image, then lo image
 constexpr int C1S_WBYTES = C1S_WHALFS * 2;           // 43008
 
-template <typename TO, bool ALIGNED>
+template <typename TO, int SRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wt1s, const float *__restrict__ bias,
+void conv1_split_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1s, const float *__restrict__ bias,
                         TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
   constexpr int NT = 256;
   constexpr int WLOADS = (C1S_WBYTES / 16 + NT - 1) / NT;    // 11 float4
@@ -511,12 +677,15 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   const int b = blk / Ho;
   const int wo0 = wt_i * C1_TILE;
 
-  const long row_elems = (long)W * kConv1Cin;
-  Conv1Row<NT, C1S_IN4, ALIGNED> row;
-  row.init(tid, wo0, row_elems, C1S_SEG);
+  typedef typename Conv1RowSel<NT, C1S_IN4, SRC>::type Row;
+  Row row;
+  row.init(src, tid, b, wo0, H, W, C1S_SEG);
+  if constexpr (Row::kRing) {
+    for (int e = tid; e < C1S_SEG / 2; e += NT) in_hi[e] = in_lo[e] = 0u;
+  }
   floatx4 w_reg[WLOADS];
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
-    row.load(x, b, H, row_elems, ho, kh);
+    row.load(ho, kh);
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1s + (size_t)kh * C1S_WHALFS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -526,19 +695,27 @@ void conv1_split_kernel(const float *__restrict__ x, const _Float16 *__restrict_
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    if constexpr (Row::kRing) {
+      row.scatter([&](int e, float v) __attribute__((always_inline)) {
+        const _Float16 hv = (_Float16)v;
+        reinterpret_cast<_Float16 *>(in_hi)[e] = hv;
+        reinterpret_cast<_Float16 *>(in_lo)[e] = (_Float16)(v - (float)hv);
+      });
+    } else {
 #pragma unroll
-    for (int i = 0; i < C1S_IN4; ++i) {
-      const int q = tid + NT * i;
-      const floatx4 v = row.scaled(i);   // then the two pieces
-      half4_t hv, lv;
+      for (int i = 0; i < C1S_IN4; ++i) {
+        const int q = tid + NT * i;
+        const floatx4 v = row.scaled(i);   // then the two pieces
+        half4_t hv, lv;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hv[j] = (_Float16)v[j];
-        lv[j] = (_Float16)(v[j] - (float)hv[j]);
-      }
-      if (q < C1S_SEG / 4) {
-        reinterpret_cast<half4_t *>(in_hi)[q] = hv;
-        reinterpret_cast<half4_t *>(in_lo)[q] = lv;
+        for (int j = 0; j < 4; ++j) {
+          hv[j] = (_Float16)v[j];
+          lv[j] = (_Float16)(v[j] - (float)hv[j]);
+        }
+        if (q < C1S_SEG / 4) {
+          reinterpret_cast<half4_t *>(in_hi)[q] = hv;
+          reinterpret_cast<half4_t *>(in_lo)[q] = lv;
+        }
       }
     }
 #pragma unroll

@@ -181,7 +181,9 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
     perr = np.abs(out[21].cpu().numpy() - rpred[0]).max(axis=2)
     print("cfg4 window 21: F_t error %.3g, pixels max %.3g median %.3g outside %d border pixels"
           % (err, perr[~mask].max(), np.median(perr), int(mask.sum())))
-    assert perr[~mask].max() < 3e-3, "window 21: pixel error %.3g" % perr[~mask].max()
+    # measured (round 3): F_t 9.7e-7, pixels 9.6e-4 max / 8.8e-5 median outside 476 border pixels -- at the 1e-3 target,
+    # not inside it with margin: 1.9e-3 px of F_t error + 3e-3 px of float32 map evaluation, times a gradient of 0.2
+    assert perr[~mask].max() < 1.5e-3, "window 21: pixel error %.3g" % perr[~mask].max()
     assert mask.mean() < 0.005
     del out, o1, rpred, perr
     # the warp stage of configs[4] (float32 in both modes) at 4K: zero control vectors -> identity grid

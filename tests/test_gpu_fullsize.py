@@ -173,8 +173,9 @@ def test_tps_warp_4k_against_oracle(dev):
     err = np.abs(out.cpu().numpy()[0] - ref[0]).max(axis=2)
     print("4K TPS warp vs oracle: grid error %.3g px (x) %.3g px (y); pixels max %.3g, median %.3g outside %d border pixels "
           "(%.4f%% of the frame)" % (ex.max(), ey.max(), err[~mask].max(), np.median(err), int(mask.sum()), 100 * mask.mean()))
-    assert max(ex.max(), ey.max()) < 3e-2, "grid error %.3g px" % max(ex.max(), ey.max())
-    assert err[~mask].max() < 2e-3, "pixel error %.3g" % err[~mask].max()
+    # measured (round 3, MI355X): grid 3.1e-3 px (x) / 9.7e-4 px (y), pixels 2.0e-4 max, 5.5e-6 median, 732 border pixels
+    assert max(ex.max(), ey.max()) < 1e-2, "grid error %.3g px" % max(ex.max(), ey.max())
+    assert err[~mask].max() < 1e-3, "pixel error %.3g" % err[~mask].max()      # BASELINE.json's bound, at 4K
     # a warped value may move by the coordinate error times the gradient and no more
     assert (err - 0.25 * (ex + ey).reshape(h, w))[~mask].max() < 2e-5
     assert mask.mean() < 0.005

@@ -362,7 +362,7 @@ def test_tps_large_displacement_out_of_frame(dev, frames):
     ex = np.abs(xs - xo).reshape(B, H, W) * W / 2
     ey = np.abs(ys - yo).reshape(B, H, W) * H / 2
     print("large displacement (%s): outside %.0f%%, grid error %.3g px, |T| max %.3g" % (frames, 100 * outside.mean(), max(ex.max(), ey.max()), np.abs(T).max()))
-    assert max(ex.max(), ey.max()) < 2e-2           # |T| is ~10x the small-vector cases': float32 evaluation noise scales with it
+    assert max(ex.max(), ey.max()) < 5e-3           # measured 7.5e-4 px at 128 x 72 (|T| up to 4: ~10x the small-vector cases')
     mask = otps.border_discontinuity_mask(xo, yo, H, W, delta=3e-2).reshape(B, H, W)
     err = np.abs(out - ref).max(axis=3)
     assert (np.abs(out).max(axis=3)[outside] <= noise[outside]).all(), "outside the frame the taps must cancel"
