@@ -56,6 +56,10 @@ SIGNATURES = {
     "dvsg_frames_u8_to_f32": [_vp, ctypes.c_size_t, _i, _vp, _vp],
     "dvsg_frames_resize_u8_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "dvsg_window_gather_f32": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+    "dvsg_stabilize_ring_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_stabilize_ring_u8": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_locnet_forward_ring": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, ctypes.POINTER(_i), _vp,
+                                 ctypes.c_size_t, _vp],
     "dvsg_frames_f32_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_frames_f64_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_debug_set_option": [ctypes.c_char_p, _i],

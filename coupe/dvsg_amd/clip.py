@@ -133,10 +133,10 @@ def stabilize_clip(model, session, frames, skip_length=SKIP_LENGTH, side_by_side
         cast TF applies to the fed window (eval.py:106-110).
     Video decode / encode (cv2.VideoCapture / VideoWriter) is host I/O and out of scope.
 
-    The clip lives in one HBM pool [2N,h,w,3] float32 (unstable | stabilised).  Each step is
-    `dvsg_window_gather_f32` (the 21-channel window, eval.py:103-104, picked through
-    `window_index_table`) + `dvsg_stabilize_*` writing straight into the pool; the write-back of
-    eval.py:116-120 is the index table, not a copy.  `session` is accepted for call-site
+    The clip lives in one HBM pool [2N,h,w,3] float32 (unstable | stabilised).  Each step is ONE call,
+    `dvsg_stabilize_ring_f32`: conv1 assembles the 21-channel window of eval.py:103-104 in its load stage
+    from the pool frames `window_index_table` names, and the result is written straight into its pool
+    slot; the write-back of eval.py:116-120 is the index table, not a copy.  `session` is accepted for call-site
     symmetry with eval.py and not used.
 
     Returns the stabilised frames [N,h,w,3] -- float32, or uint8 (np.uint8(x * 255.),
@@ -182,12 +182,12 @@ def stabilize_clip(model, session, frames, skip_length=SKIP_LENGTH, side_by_side
             left_done = True
     else:
         raise TypeError("frames must be uint8 or floating point, got %s" % fr.dtype)
-    patches = torch.empty((1, h, w, 3 * S), dtype=torch.float32, device=dev)
     F = torch.empty((1, model.param_dim, 2), dtype=torch.float32, device=dev)
+    # one call per frame: conv1 picks the 7 window frames out of the pool through table[k] (eval.py:103-104 fused
+    # into its load stage: no window tensor, no gather launch), the warp reads u_t = pool[table[k, 6]] = pool[k],
+    # and the result lands in its history slot pool[N + k] (:116), which no slot of window k reads
     for k in range(N):                                                             # eval.py:101
-        _lib.call("dvsg_window_gather_f32", ptr(pool), 2 * N, h, w, ptr(table[k]), 1, S, ptr(patches), stream())
-        model.locnet.stabilize(patches, pool[k:k + 1], pool[N + k:N + k + 1], F,   # :106-110, :116
-                               precision=model.precision)
+        model.locnet.stabilize_ring(pool, table[k:k + 1], pool[N + k:N + k + 1], F, precision=model.precision)  # :106-110
     stab = pool[N:]
     if side_by_side:                                                               # eval.py:112-113
         if not left_done:   # uint8 / float32 input: the float32 pool holds the frame exactly
@@ -270,19 +270,20 @@ def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length
     _check_window(model, S)
     span = int(skip_length[-1])
     table = torch.from_numpy(teacher_forced_index_table(N, skip_length)).to(dev)
-    pool = torch.empty((2 * N, h, w, 3), dtype=torch.float32, device=dev)
-    _frames_to_pool(un, pool[:N], h, w, flip, "unstable")
-    _frames_to_pool(st, pool[N:], h, w, flip, "stable")
-    patches = torch.empty((batch, h, w, 3 * S), dtype=torch.float32, device=dev)
+    if un.dtype == torch.uint8 and st.dtype == torch.uint8 and tuple(un.shape[1:3]) == (h, w) and not flip:
+        pool = torch.cat([un, st], 0)        # the raw frames ARE the ring: 3 bytes per pixel in HBM
+    else:
+        pool = torch.empty((2 * N, h, w, 3), dtype=torch.float32, device=dev)
+        _frames_to_pool(un, pool[:N], h, w, flip, "unstable")
+        _frames_to_pool(st, pool[N:], h, w, flip, "stable")
     F = torch.empty((batch, model.param_dim, 2), dtype=torch.float32, device=dev)
 
     def produce(b0, b1):
         b = b1 - b0
-        _lib.call("dvsg_window_gather_f32", ptr(pool), 2 * N, h, w, ptr(table[b0]), b, S, ptr(patches), stream())
         out = torch.empty((b, h, w, 3), dtype=torch.float32, device=dev)
-        # u_t of windows b0..b1 are the consecutive unstable frames b0+32 .. b1+32: a slice of the pool
-        model.locnet.stabilize(patches[:b], pool[b0 + span:b1 + span], out, F[:b], n_streams=model.n_streams,
-                               precision=model.precision)
+        # windows b0..b1 straight from the pool (uint8 when the clips came as same-size RGB uint8 frames: the / 255. of
+        # eval_train.py's frame reader happens in conv1's load stage); u_t of window k is pool frame table[k, 6] = k + 32
+        model.locnet.stabilize_ring(pool, table[b0:b1], out, F[:b], precision=model.precision)
         if not as_uint8:
             return out
         out8 = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)

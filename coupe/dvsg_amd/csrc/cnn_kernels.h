@@ -96,8 +96,17 @@ constexpr int kConv1Ld = 150;            // LDS / global row stride (2*odd: conf
 // wt1h (float16 precision only): the same row as [7][64][kConv1LdH] float16, zero-padded to 160.
 constexpr int kConv1LdH = 168;
 // wt1s ("f32s" precision only): float16 pieces [7][2][64][kConv1LdH], same tap positions: hi = f16(w), lo = f16((w - hi) * 2^11).
-int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const void *wt1s, const float *bias,
-                 void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
+// conv1's input: the window tensor [B,H,W,21] float32 the reference feeds (eval.py:106-110), or -- SURVEY.md 8f-1/-2 --
+// a pool of RGB frames [n_pool,H,W,3] (float32 in [0,1], or raw uint8 whose / 255. is fused) plus the table [B,7] of
+// the pool frame in each window slot, oldest to newest: the np.concatenate of eval.py:103-104 happens in the load stage.
+enum Conv1SrcKind { kSrcWindow = 0, kSrcRingF32 = 1, kSrcRingU8 = 2 };
+struct Conv1Src {
+  const void *base;   // window tensor, or frame pool
+  const int *table;   // ring: [B,7] pool indices (device); an index outside [0, n_pool) stages zeros
+  int n_pool;
+};
+int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *wt1, const void *wt1h, const void *wt1s,
+                 const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
 
 // 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 8 == 0.
 int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,

@@ -46,6 +46,10 @@ int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const 
                   int W, int C, int P, int out_h, int out_w, float *out, float *x_s, float *y_s,
                   void *stream);
 
+int tps_warp_ring_impl(const void *pool, int pool_is_u8, int n_pool, const int *table, int tstride, const float *coord,
+                       long coord_bstride, const float *T, int B, int H, int W, int P, float *out, float *x_s, float *y_s,
+                       void *stream);
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dvsg

@@ -1,6 +1,8 @@
 // Root of resnet_v1_50 (slim `conv2d_same(64, 7, stride=2)` + BatchNorm + ReLU, then
 // `max_pool2d(3x3, stride 2, SAME)`) with scale_RGB (networks.py:6-16) fused into conv1's
 // load stage.
+#include <cstdint>
+
 #include "cnn_device.h"
 #include "cnn_kernels.h"
 
@@ -143,6 +145,7 @@ struct Conv1RingRow {
   int l0[GROUPS];          // LDS element of the first value's PIXEL (channel 3 f of it)
   unsigned phase;          // 2 bits per group: rgb of the group's first value
   unsigned col_ok, st_ok;  // per element: inside the image row / inside the staged segment
+  unsigned no_frame;       // per group: its window slot names a frame outside the pool (reads as a frame of zeros)
   floatx4 regf[kU8 ? 1 : GROUPS];
   unsigned regu[kU8 ? GROUPS : 1];
   bool row_ok;
@@ -156,7 +159,7 @@ struct Conv1RingRow {
     pool = static_cast<const TS *>(src.base);
     const long frame_elems = (long)H * row_elems;
     const long r_first = (long)(2 * wo0 - 4) * 3;    // one pixel before the segment: a multiple of 4
-    col_ok = st_ok = phase = 0;
+    col_ok = st_ok = phase = no_frame = 0;
     row_ok = false;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
@@ -174,11 +177,12 @@ struct Conv1RingRow {
         const int grp = c / (kConv1Cin / 3);
         mean[4 * i + j] = grp == 0 ? 123.68f : (grp == 1 ? 116.779f : 103.939f);
         if (in_range && t >= 3 && t < 3 * (C1_RING_PX + 1)) ms |= 1u << j;
-        if (frame_ok && r0 + j >= 0 && r0 + j < row_elems) mc |= 1u << j;
+        if (in_range && r0 + j >= 0 && r0 + j < row_elems) mc |= 1u << j;
       }
+      if (in_range && !frame_ok) no_frame |= 1u << i;   // raw value 0 (scaled: -mean), read from the pool's frame 0 and dropped
       // ALIGNED: a group lies inside the row or outside it as a whole (both ends of the row and the run's start are
-      // multiples of four elements); outside -- or with a frame index outside the pool -- it reads row `hc` of the pool's
-      // first frame and its values are dropped.  Element-wise otherwise.
+      // multiples of four elements); outside it reads row `hc` of the pool's first frame and its values are dropped.
+      // Element-wise otherwise.
       const bool whole = mc == 15u;
       if (ALIGNED && !whole) mc = 0;
       col_ok |= mc << (4 * i);
@@ -232,6 +236,7 @@ struct Conv1RingRow {
         float raw;
         if constexpr (kU8) raw = (float)((regu[i] >> (8 * j)) & 255u);   // == f32(v / 255.) * 255.f, exactly
         else raw = regf[i][j] * 255.0f;
+        if ((no_frame >> i) & 1u) raw = 0.f;
         const float v = ((ok >> (4 * i + j)) & 1u) ? raw - mean[4 * i + j] : 0.f;
         const int t = ph + j, step = t / 3;                              // t in 0..5
         if ((st_ok >> (4 * i + j)) & 1u) put(l0[i] + kConv1Cin * step + (t - 3 * step), v);
@@ -839,47 +844,55 @@ int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 wa
 
 void set_conv1_variant(int v) { g_conv1_variant = v; }
 
-int launch_conv1(int out_prec, const float *x, const float *wt1, const void *wt1h, const void *wt1s, const float *bias,
-                 void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s) {
+int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *wt1, const void *wt1h, const void *wt1s,
+                 const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s) {
   const int wtiles = ceil_div(Wo, C1_TILE);
   const long blocks = (long)wtiles * Ho * B;
   DVSG_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv1: grid of %ld workgroups out of range", blocks);
   DVSG_REQUIRE((long)W * kConv1Cin < (1L << 31), "conv1: input row too long");
-  ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,
-                 4.0 * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
+  DVSG_REQUIRE(src_kind == kSrcWindow || (src.table && src.n_pool > 0), "conv1: a frame ring needs its index table");
+  const double in_bytes = src_kind == kSrcRingU8 ? 1.0 : 4.0;   // each window element once (ring frames are shared by windows:
+  ProfScope prof(kClsConv1, s, 2.0 * (double)B * Ho * Wo * 64 * 49 * kConv1Cin,   // an upper bound of the algorithmic read)
+                 in_bytes * (double)B * H * W * kConv1Cin + (double)elem_size(out_prec) * B * Ho * Wo * 64);
   const dim3 grid((unsigned)blocks);
-  // rows that start on 16-byte boundaries: the kernels' staged segment then consists of whole aligned groups
-  const bool aligned = W % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+  // rows that start on 16-byte boundaries (4-byte for uint8 frames): the staged segment then consists of whole aligned groups
+  const bool aligned = W % 4 == 0 && reinterpret_cast<uintptr_t>(src.base) % (src_kind == kSrcRingU8 ? 4 : 16) == 0;
+  const int SRC = 2 * src_kind + (aligned ? 1 : 0);
   // the f32s activations are float16 pieces (P format): only conv1_split_kernel writes them, whatever the A/B switch says
   // (the float32 kernel's output would be read back as pieces: silent garbage)
   if (out_prec == kF32S && !wt1s) return fail(DVSG_ERR_UNSUPPORTED, "conv1: the f32s precision needs the piece weights");
+#define DVSG_K_F32(SRC) conv1_kernel<4, float, SRC>
+#define DVSG_K_F16(SRC) conv1_f16_kernel<_Float16, SRC>
+#define DVSG_K_SPLIT(SRC) conv1_split_kernel<float, SRC>
+#define DVSG_C1(KERNEL, NTHREADS, WPTR, YPTR)                                                                            \
+  do {                                                                                                                   \
+    switch (SRC) {                                                                                                       \
+      case 0: hipLaunchKernelGGL((KERNEL(0)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 1: hipLaunchKernelGGL((KERNEL(1)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 2: hipLaunchKernelGGL((KERNEL(2)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 3: hipLaunchKernelGGL((KERNEL(3)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 4: hipLaunchKernelGGL((KERNEL(4)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      default: hipLaunchKernelGGL((KERNEL(5)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+    }                                                                                                                    \
+  } while (0)
   if (out_prec == kF32S) {
-    if (aligned)
-      hipLaunchKernelGGL((conv1_split_kernel<float, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
-                         bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
-    else
-      hipLaunchKernelGGL((conv1_split_kernel<float, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1s),
-                         bias, static_cast<float *>(y), H, W, Ho, Wo, wtiles);
+    DVSG_C1(DVSG_K_SPLIT, 256, static_cast<const _Float16 *>(wt1s), static_cast<float *>(y));
   } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
-    if (aligned)
-      hipLaunchKernelGGL((conv1_f16_kernel<_Float16, true>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
-                         bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
-    else
-      hipLaunchKernelGGL((conv1_f16_kernel<_Float16, false>), grid, dim3(256), 0, s, x, static_cast<const _Float16 *>(wt1h),
-                         bias, static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
-  } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output
-    hipLaunchKernelGGL((conv1_kernel<4, _Float16, false>), grid, dim3(256), 0, s, x, wt1, bias,
-                       static_cast<_Float16 *>(y), H, W, Ho, Wo, wtiles);
-  } else if (g_conv1_variant != 0) {
-    hipLaunchKernelGGL((conv1_kernel<8, float, false>), grid, dim3(512), 0, s, x, wt1, bias, static_cast<float *>(y), H,
-                       W, Ho, Wo, wtiles);
-  } else if (aligned) {
-    hipLaunchKernelGGL((conv1_kernel<4, float, true>), grid, dim3(256), 0, s, x, wt1, bias, static_cast<float *>(y), H,
-                       W, Ho, Wo, wtiles);
+    DVSG_C1(DVSG_K_F16, 256, static_cast<const _Float16 *>(wt1h), static_cast<_Float16 *>(y));
+  } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output (window tensors only)
+    DVSG_REQUIRE(src_kind == kSrcWindow, "conv1: conv1_variant 2 takes a window tensor");
+    hipLaunchKernelGGL((conv1_kernel<4, _Float16, 0>), grid, dim3(256), 0, s, src, wt1, bias, static_cast<_Float16 *>(y), H, W,
+                       Ho, Wo, wtiles);
+  } else if (g_conv1_variant != 0 && src_kind == kSrcWindow) {
+    hipLaunchKernelGGL((conv1_kernel<8, float, 0>), grid, dim3(512), 0, s, src, wt1, bias, static_cast<float *>(y), H, W, Ho,
+                       Wo, wtiles);
   } else {
-    hipLaunchKernelGGL((conv1_kernel<4, float, false>), grid, dim3(256), 0, s, x, wt1, bias, static_cast<float *>(y), H,
-                       W, Ho, Wo, wtiles);
+    DVSG_C1(DVSG_K_F32, 256, wt1, static_cast<float *>(y));
   }
+#undef DVSG_C1
+#undef DVSG_K_F32
+#undef DVSG_K_F16
+#undef DVSG_K_SPLIT
   return check_launch("conv1_kernel");
 }
 

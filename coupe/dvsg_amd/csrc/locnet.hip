@@ -300,10 +300,10 @@ int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, v
 }
 
 // Runs the network in precision `prec`; stop_stage < 0 runs everything and writes F_t [B,50].
-int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H, int W, float *F_t, int stop_stage,
+int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind, int B, int H, int W, float *F_t, int stop_stage,
             float *act_out, size_t act_out_bytes, int *act_dims, void *workspace, size_t workspace_bytes,
             hipStream_t s) {
-  DVSG_REQUIRE(net && patches && workspace, "locnet forward: NULL pointer");
+  DVSG_REQUIRE(net && src.base && workspace, "locnet forward: NULL pointer");
   DVSG_REQUIRE(B > 0 && H >= 1 && W >= 1, "locnet forward: bad shape B=%d H=%d W=%d", B, H, W);
   DVSG_REQUIRE(((uintptr_t)workspace & 255) == 0, "locnet forward: workspace must be 256-byte aligned");
   const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
@@ -342,8 +342,8 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
   DVSG_RUN(launch_zero_tickets(ws.splitk_counters, (size_t)kMaxConvLaunches * kSplitKMaxTiles, s));
   int launch_idx = 0;
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
-  DVSG_RUN(launch_conv1(prec, patches, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s, net->conv1.bias, ws.bufA, B, H,
-                        W, d.H1, d.W1, s));
+  DVSG_RUN(launch_conv1(prec, src, src_kind, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s, net->conv1.bias, ws.bufA, B,
+                        H, W, d.H1, d.W1, s));
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
   DVSG_RUN(launch_maxpool(prec, ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
   DVSG_TAP(1, ws.bufB, d.Hp, d.Wp, 64);
@@ -420,6 +420,14 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
 #undef DVSG_RUN
 }
 
+int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H, int W, float *F_t, int stop_stage,
+            float *act_out, size_t act_out_bytes, int *act_dims, void *workspace, size_t workspace_bytes,
+            hipStream_t s) {
+  const Conv1Src src{patches, nullptr, 0};
+  return forward(net, prec, src, kSrcWindow, B, H, W, F_t, stop_stage, act_out, act_out_bytes, act_dims, workspace,
+                 workspace_bytes, s);
+}
+
 int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const float *u_t, int B, int H, int W,
               float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
               void *stream) {
@@ -435,6 +443,29 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
   // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111); float32
   if (int rc = tps_apply_impl(net->winv, net->v_src, F, 1, B, 25, ws.T, stream)) return rc;
   return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
+}
+
+// The evaluation graph fed from a frame ring: window b = pool frames table[b][0..6], u_t = its newest
+// frame table[b][6]; conv1 assembles the window in its load stage (eval.py:103-104) and, for a uint8 pool, applies the
+// / 255. of eval.py:80 there; the warp reads u_t from the pool through the same table.
+int stabilize_ring(const dvsg_locnet *net, int prec, const void *pool, int pool_is_u8, int n_pool, const int32_t *table,
+                   int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
+                   size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(net && pool && table && s_t_pred && workspace, "dvsg_stabilize_ring: NULL pointer");
+  DVSG_REQUIRE(B > 0 && B <= 65535 && n_pool > 0, "dvsg_stabilize_ring: B=%d n_pool=%d out of range", B, n_pool);
+  DVSG_REQUIRE(prec == kF32 || prec == kF16 || prec == kF32S, "dvsg_stabilize_ring: unknown precision %d", prec);
+  DVSG_REQUIRE(net->c_in == 21, "dvsg_stabilize_ring: the ring holds RGB frames, 7 per window");
+  const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
+  if (ws.total > workspace_bytes)
+    return fail(DVSG_ERR_WORKSPACE, "dvsg_stabilize_ring: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
+  float *F = F_t ? F_t : ws.Ft;
+  const Conv1Src src{pool, table, n_pool};
+  if (int rc = forward(net, prec, src, pool_is_u8 ? kSrcRingU8 : kSrcRingF32, B, H, W, F, -1, nullptr, 0, nullptr, workspace,
+                       workspace_bytes, as_stream(stream)))
+    return rc;
+  if (int rc = tps_apply_impl(net->winv, net->v_src, F, 1, B, 25, ws.T, stream)) return rc;
+  return tps_warp_ring_impl(pool, pool_is_u8, n_pool, table + 6, 7, net->v_src, 0, ws.T, B, H, W, 25, s_t_pred, x_s, y_s,
+                            stream);
 }
 
 int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const float *bias, const void *res, void *y, int B,
@@ -716,6 +747,37 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                        void *stream) {
   return stabilize(net, kF16, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+}
+
+static int ring_precision(int precision) {
+  return precision == DVSG_PRECISION_F32 ? kF32 : precision == DVSG_PRECISION_F16 ? kF16 : precision == DVSG_PRECISION_F32S ? kF32S : -1;
+}
+
+int dvsg_stabilize_ring_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool, const int32_t *table,
+                            int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  return stabilize_ring(net, ring_precision(precision), pool, 0, n_pool, table, B, H, W, s_t_pred, F_t, x_s, y_s, workspace,
+                        workspace_bytes, stream);
+}
+
+int dvsg_stabilize_ring_u8(const dvsg_locnet_t *net, int precision, const uint8_t *pool, int n_pool, const int32_t *table,
+                           int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+  return stabilize_ring(net, ring_precision(precision), pool, 1, n_pool, table, B, H, W, s_t_pred, F_t, x_s, y_s, workspace,
+                        workspace_bytes, stream);
+}
+
+int dvsg_locnet_forward_ring(const dvsg_locnet_t *net, int precision, const void *pool, int pool_is_u8, int n_pool,
+                             const int32_t *table, int B, int H, int W, int stage, float *out, size_t out_bytes,
+                             int *act_dims_host, void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(pool && table && out && n_pool > 0, "dvsg_locnet_forward_ring: bad arguments");
+  DVSG_REQUIRE(stage >= -1 && stage <= 18 && (stage < 0 || act_dims_host), "dvsg_locnet_forward_ring: stage %d outside [-1,18]", stage);
+  DVSG_REQUIRE(stage >= 0 || out_bytes >= (size_t)B * 50 * sizeof(float), "dvsg_locnet_forward_ring: F_t needs B*50 floats");
+  const int prec = ring_precision(precision);
+  DVSG_REQUIRE(prec >= 0, "dvsg_locnet_forward_ring: unknown precision %d", precision);
+  const Conv1Src src{pool, table, n_pool};
+  return forward(net, prec, src, pool_is_u8 ? kSrcRingU8 : kSrcRingF32, B, H, W, stage < 0 ? out : nullptr, stage,
+                 stage < 0 ? nullptr : out, out_bytes, act_dims_host, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -14,6 +14,8 @@
 // parity tests compare source coordinates to the oracle within 1-2 ulp (only logf differs).
 #include <vector>
 
+#include <cstdint>
+
 #include "common.h"
 
 namespace dvsg {
@@ -186,6 +188,16 @@ __device__ __forceinline__ Pix<C> load_pix(const float *__restrict__ p) {
   for (int c = 0; c < C; ++c) r.v[c] = p[c];
   return r;
 }
+// a uint8 frame: the pixel as eval.py:80 hands it to the graph, float32(v / 255.) -- the float64 quotient rounded
+// once.  A correctly rounded float32 division gives the same value for all 256 bytes (exhaustive:
+// tests/test_frames_cpu.py); hipcc's `/` is correctly rounded (no -ffast-math in this build).
+template <int C>
+__device__ __forceinline__ Pix<C> load_pix(const uint8_t *__restrict__ p) {
+  Pix<C> r;
+#pragma unroll
+  for (int c = 0; c < C; ++c) r.v[c] = (float)p[c] / 255.0f;
+  return r;
+}
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -211,8 +223,8 @@ struct TapsA<0> {  // generic channel count: the blend reads through the tap poi
 
 // Address + weight computation and the four tap loads; the loads are only ISSUED here, so the
 // caller can do other work before sample_a_blend() needs them.
-template <int C>
-__device__ __forceinline__ void sample_a_load(const float *__restrict__ img /* [H,W,C] of this sample */,
+template <int C, typename TU = float>
+__device__ __forceinline__ void sample_a_load(const TU *__restrict__ img /* [H,W,C] of this sample */,
                                               int H, int W, int Cn, float xs, float ys, TapsA<C> &t) {
   const float x = ((xs + 1.0f) * (float)W) / 2.0f;  // :48
   const float y = ((ys + 1.0f) * (float)H) / 2.0f;  // :49
@@ -229,10 +241,10 @@ __device__ __forceinline__ void sample_a_load(const float *__restrict__ img /* [
   t.wb = (x1f - x) * (y - y0f);
   t.wc = (x - x0f) * (y1f - y);
   t.wd = (x - x0f) * (y - y0f);
-  const float *pa = img + ((size_t)y0 * W + x0) * Cn;  // (x0,y0)
-  const float *pb = img + ((size_t)y1 * W + x0) * Cn;  // (x0,y1)
-  const float *pc = img + ((size_t)y0 * W + x1) * Cn;  // (x1,y0)
-  const float *pd = img + ((size_t)y1 * W + x1) * Cn;  // (x1,y1)
+  const TU *pa = img + ((size_t)y0 * W + x0) * Cn;  // (x0,y0)
+  const TU *pb = img + ((size_t)y1 * W + x0) * Cn;  // (x0,y1)
+  const TU *pc = img + ((size_t)y0 * W + x1) * Cn;  // (x1,y0)
+  const TU *pd = img + ((size_t)y1 * W + x1) * Cn;  // (x1,y1)
   if constexpr (C > 0) {
     t.a = load_pix<C>(pa);
     t.b = load_pix<C>(pb);
@@ -373,12 +385,16 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 constexpr int kTpsRows = 4;
 constexpr float kLn2 = 0x1.62e43p-1f;
 
-template <int C>
+// U is [B,H,W,C], or -- u_index given -- a pool of frames [n_pool,H,W,C] of which sample b reads frame
+// u_index[b * u_stride] (the frame ring of dvsg_stabilize_ring_*: u_t is the newest frame of the window; an index
+// outside the pool reads as a zero frame, like dvsg_window_gather_f32).  TU = uint8_t: raw frames, / 255. fused.
+template <int C, typename TU = float>
 __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
-    const float *__restrict__ U, const float *__restrict__ coord, long coord_bstride,
+    const TU *__restrict__ U, const float *__restrict__ coord, long coord_bstride,
     const float *__restrict__ T, int H, int W, int Cn, int P, int out_h, int out_w, float step_x,
     float step_y, float *__restrict__ out,
-    float *__restrict__ xs_out, float *__restrict__ ys_out) {
+    float *__restrict__ xs_out, float *__restrict__ ys_out, const int *__restrict__ u_index = nullptr, int u_stride = 0,
+    int n_pool = 0) {
   __shared__ float4 sp[64];      // {px, py, T[0][3+k], T[1][3+k]}
   __shared__ float4 sdy[64];     // (y_t[r] - py)^2 for the 4 rows of this workgroup
   __shared__ float sa[6];        // T[0][0..2], T[1][0..2]
@@ -404,7 +420,14 @@ __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
   const int j = blockIdx.x * kThreads + t;
   if (j >= out_w) return;
   const float x_t = -1.0f + step_x * (float)j;  // tf.linspace: start + step * i (:94)
-  const float *img = U ? U + (size_t)b * H * W * Cn : nullptr;
+  int frame = b;
+  bool frame_ok = true;
+  if (u_index) {
+    frame = u_index[(size_t)b * u_stride];
+    frame_ok = frame >= 0 && frame < n_pool;
+    if (!frame_ok) frame = 0;
+  }
+  const TU *img = U ? U + (size_t)frame * H * W * Cn : nullptr;
 
   floatx2 xs2[2], ys2[2];
 #pragma unroll
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
     const size_t pix = ((size_t)b * out_h + i) * out_w + j;
     if (xs_out) xs_out[pix] = xs[r];
     if (ys_out) ys_out[pix] = ys[r];
-    if (img) sample_a_load<C>(img, H, W, Cn, xs[r], ys[r], taps[r]);  // all 16 tap loads in flight
+    if (img) sample_a_load<C, TU>(img, H, W, Cn, xs[r], ys[r], taps[r]);  // all 16 tap loads in flight
   }
   if (!img) return;
 #pragma unroll
@@ -451,6 +474,12 @@ __global__ __launch_bounds__(kThreads) void tps_warp_kernel(
     if (i >= out_h) break;
     float v[C > 0 ? C : kMaxGenericC];
     sample_a_blend<C>(taps[r], Cn, v);
+    if constexpr (C > 0) {
+      if (!frame_ok) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = 0.f;
+      }
+    }
     store_pix<C>(out, ((size_t)b * out_h + i) * out_w + j, Cn, v);
   }
 }
@@ -699,14 +728,35 @@ int tps_warp_impl(const float *U, const float *coord, long coord_bstride, const 
                      (double)B * out_h * out_w * ((x_s ? 4.0 : 0.0) + (y_s ? 4.0 : 0.0)));
   if (!U) C = 3;
   if (C == 3)
-    hipLaunchKernelGGL((tps_warp_kernel<3>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
-                       C, P, out_h, out_w, sx, sy, out, x_s, y_s);
+    hipLaunchKernelGGL((tps_warp_kernel<3, float>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
+                       C, P, out_h, out_w, sx, sy, out, x_s, y_s, (const int *)nullptr, 0, 0);
   else if (C == 1)
-    hipLaunchKernelGGL((tps_warp_kernel<1>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
-                       C, P, out_h, out_w, sx, sy, out, x_s, y_s);
+    hipLaunchKernelGGL((tps_warp_kernel<1, float>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
+                       C, P, out_h, out_w, sx, sy, out, x_s, y_s, (const int *)nullptr, 0, 0);
   else
-    hipLaunchKernelGGL((tps_warp_kernel<0>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
-                       C, P, out_h, out_w, sx, sy, out, x_s, y_s);
+    hipLaunchKernelGGL((tps_warp_kernel<0, float>), grid, dim3(kThreads), 0, s, U, coord, coord_bstride, T, H, W,
+                       C, P, out_h, out_w, sx, sy, out, x_s, y_s, (const int *)nullptr, 0, 0);
+  return check_launch("tps_warp_kernel");
+}
+
+// u_t = frame table[b * tstride] of a pool [n_pool,H,W,3] (float32, or uint8 with / 255. fused), same-size output
+int tps_warp_ring_impl(const void *pool, int pool_is_u8, int n_pool, const int *table, int tstride, const float *coord,
+                       long coord_bstride, const float *T, int B, int H, int W, int P, float *out, float *x_s, float *y_s,
+                       void *stream) {
+  DVSG_REQUIRE(pool && table && coord && T && out, "tps_warp_ring: NULL pointer");
+  DVSG_REQUIRE(n_pool > 0 && tstride > 0 && P >= 1 && P <= kMaxPts, "tps_warp_ring: bad arguments");
+  if (int rc = check_image_args("tps_warp_ring", B, H, W, 3, H, W)) return rc;
+  dim3 grid(ceil_div(W, kThreads), ceil_div(H, kTpsRows), B);
+  const float sx = lin_step(W), sy = lin_step(H);
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(kClsTpsWarp, s, 0.0, (pool_is_u8 ? 3.0 : 12.0) * B * H * W + 12.0 * B * H * W +
+                                          (double)B * H * W * ((x_s ? 4.0 : 0.0) + (y_s ? 4.0 : 0.0)));
+  if (pool_is_u8)
+    hipLaunchKernelGGL((tps_warp_kernel<3, uint8_t>), grid, dim3(kThreads), 0, s, static_cast<const uint8_t *>(pool), coord,
+                       coord_bstride, T, H, W, 3, P, H, W, sx, sy, out, x_s, y_s, table, tstride, n_pool);
+  else
+    hipLaunchKernelGGL((tps_warp_kernel<3, float>), grid, dim3(kThreads), 0, s, static_cast<const float *>(pool), coord,
+                       coord_bstride, T, H, W, 3, P, H, W, sx, sy, out, x_s, y_s, table, tstride, n_pool);
   return check_launch("tps_warp_kernel");
 }
 

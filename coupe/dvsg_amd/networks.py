@@ -129,6 +129,64 @@ class LocNet(object):
             join.record(side)
             cur.wait_event(join)
 
+    _PRECISION_CODE = {"f32": 0, "f16": 1, "f32s": 2}   # DVSG_PRECISION_* of include/dvsg_amd.h
+
+    def _check_ring(self, pool, table):
+        import torch
+        if self.in_channels != 21:
+            raise ValueError("a frame ring feeds 7-frame windows; conv1 of the loaded checkpoint has %d input channels"
+                             % self.in_channels)
+        if pool.dim() != 4 or pool.shape[3] != 3 or pool.dtype not in (torch.float32, torch.uint8) \
+                or not pool.is_cuda or not pool.is_contiguous():
+            raise ValueError("pool must be a contiguous [n,H,W,3] float32 or uint8 device tensor")
+        if table.dtype != torch.int32 or table.dim() != 2 or table.shape[1] != 7 or not table.is_cuda \
+                or not table.is_contiguous():
+            raise ValueError("table must be a contiguous [B,7] int32 device tensor (clip.window_index_table)")
+        return int(table.shape[0]), int(pool.shape[1]), int(pool.shape[2])
+
+    def stabilize_ring(self, pool, table, out, F, xs=None, ys=None, precision="f32"):
+        """`dvsg_stabilize_ring_f32` / `_u8`: the evaluation graph on windows assembled inside conv1's load stage
+        from the frame pool [n,H,W,3] (float32 in [0,1], or raw uint8) through the index table [B,7]
+        (eval.py:103-104 and, for uint8, the / 255. of :80, fused); u_t of window b is pool frame table[b,6]."""
+        import torch
+        B, H, W = self._check_ring(pool, table)
+        if precision not in self._PRECISION_CODE:
+            raise ValueError("precision must be 'f32', 'f32s' or 'f16', got %r" % (precision,))
+        if tuple(out.shape) != (B, H, W, 3) or F.numel() != B * 50:
+            raise ValueError("out must be [B,H,W,3] and F_t [B,25,2]")
+        for name, t, n in (("s_t_pred", out, None), ("F_t", F, None), ("x_s", xs, B * H * W), ("y_s", ys, B * H * W)):
+            if t is None:
+                continue
+            if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise ValueError("%s must be a contiguous float32 device tensor" % name)
+            if n is not None and t.numel() != n:
+                raise ValueError("%s must hold B*H*W = %d values" % (name, n))
+        ws, nbytes = self.workspace(B, H, W)
+        fn = "dvsg_stabilize_ring_u8" if pool.dtype == torch.uint8 else "dvsg_stabilize_ring_f32"
+        _lib.call(fn, self.handle, self._PRECISION_CODE[precision], ptr(pool), int(pool.shape[0]), ptr(table), B, H, W,
+                  ptr(out), ptr(F), ptr(xs), ptr(ys), ptr(ws), nbytes, stream())
+
+    def forward_ring(self, pool, table, precision="f32", stage=-1):
+        """`dvsg_locnet_forward_ring`: F_t [B,25,2] (stage -1) or the parity tap of `stage` from a frame ring."""
+        import torch
+        B, H, W = self._check_ring(pool, table)
+        ws, nbytes = self.workspace(B, H, W)
+        dims = (ctypes.c_int * 3)()
+        if stage < 0:
+            buf = torch.empty((B, 25, 2), dtype=torch.float32, device=pool.device)
+        else:
+            h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            buf = torch.empty((B * max(h1 * w1 * 64, 2048),), dtype=torch.float32, device=pool.device)
+            if stage > 1:
+                raise ValueError("forward_ring taps stages 0 (conv1) and 1 (pool1); later stages do not depend on the source")
+        _lib.call("dvsg_locnet_forward_ring", self.handle, self._PRECISION_CODE[precision], ptr(pool),
+                  1 if pool.dtype == torch.uint8 else 0, int(pool.shape[0]), ptr(table), B, H, W, int(stage), ptr(buf),
+                  buf.numel() * 4, dims, ptr(ws), nbytes, stream())
+        if stage < 0:
+            return buf
+        h, w, c = dims[0], dims[1], dims[2]
+        return buf[:B * h * w * c].reshape(B, h, w, c)
+
     def forward(self, patches, param_dim=25, precision="f32"):
         t = as_dev(patches)
         B, H, W, C = t.shape

@@ -271,6 +271,39 @@ int dvsg_frames_resize_u8_f32(const uint8_t *src, int n, int src_H, int src_W, i
  * [0, n_pool) reads as a frame of zeros. */
 int dvsg_window_gather_f32(const float *pool, int n_pool, int H, int W, const int32_t *idx, int B, int S,
                            float *patches, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The evaluation graph fed straight from a FRAME RING: what eval.py:76-81,103-110 does on the
+ * host -- frames / 255., np.concatenate of the 7 window frames on the channel axis, u_t = the newest of them --
+ * happens inside conv1's load stage and the warp's tap loads, so the [B,H,W,21] window tensor never exists.
+ *   pool   [n_pool,H,W,3] RGB frames on the device: float32 in [0,1] (dvsg_stabilize_ring_f32; e.g. the history of
+ *          eval.py:93-124, whose write-back of s_t_pred is a float frame), or the raw uint8 frames
+ *          (dvsg_stabilize_ring_u8: eval_train.py's clips, independent windows; 4x less input traffic).  uint8:
+ *          float32(v / 255.) * 255 == v exactly for every byte value, so conv1's scaled input float(v) - mean is
+ *          bit-identical to the float path's on the converted frame.
+ *   table  [B,7] int32 ON THE DEVICE: pool frame of window slot s of window b, oldest to newest (the `sample_idx`
+ *          of eval.py:103; coupe.dvsg_amd.clip.window_index_table builds it for a whole clip).  u_t of window b is
+ *          frame table[b][6].  An index outside [0, n_pool) reads as a frame of zeros (dvsg_window_gather_f32).
+ *   precision  DVSG_PRECISION_F32 (the reference's arithmetic: bit-identical to dvsg_window_gather_f32 +
+ *          dvsg_stabilize_f32 on the same frames), DVSG_PRECISION_F16, DVSG_PRECISION_F32S (same as the *_f16 / *_f32s
+ *          entry points on the gathered window).
+ * Outputs, workspace and stream as dvsg_stabilize_f32; s_t_pred may be a frame of `pool` itself only if no window
+ * of this call reads it (eval.py:116 writes the result back into the history AFTER the step).
+ * dvsg_locnet_forward_ring: the CNN alone from a ring -- F_t [B,25,2] into `out` (stage = -1), or the parity tap of
+ * `stage` (0..18, see dvsg_locnet_forward_tap_f32) with its [h,w,c] in act_dims_host.
+ * ------------------------------------------------------------------------------------- */
+#define DVSG_PRECISION_F32 0
+#define DVSG_PRECISION_F16 1
+#define DVSG_PRECISION_F32S 2
+int dvsg_stabilize_ring_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool,
+                            const int32_t *table, int B, int H, int W, float *s_t_pred, float *F_t, float *x_s,
+                            float *y_s, void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_stabilize_ring_u8(const dvsg_locnet_t *net, int precision, const uint8_t *pool, int n_pool,
+                           const int32_t *table, int B, int H, int W, float *s_t_pred, float *F_t, float *x_s,
+                           float *y_s, void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_locnet_forward_ring(const dvsg_locnet_t *net, int precision, const void *pool, int pool_is_u8, int n_pool,
+                             const int32_t *table, int B, int H, int W, int stage, float *out, size_t out_bytes,
+                             int *act_dims_host, void *workspace, size_t workspace_bytes, void *stream);
 /* eval.py:112 `np.uint8(x * 255.)`: float64 product, truncation toward zero (values outside
  * [0, 256) saturate; NumPy leaves them undefined).  src [n,H,W,3] float32 is written into columns
  * [dst_x0, dst_x0 + W) of dst [n,H,dst_W,3] uint8 -- dst_W = 2 W and dst_x0 = 0 / W give the

@@ -68,3 +68,15 @@ def test_teacher_forced_table_replays_eval_train(n, skip):
     assert np.all(got[:, :-1] >= n) and np.all(got[:, -1] < n)     # history: stable clip; current frame: unstable
     with pytest.raises(ValueError):
         teacher_forced_index_table(skip[-1], skip)
+
+
+def test_uint8_frames_survive_the_division_and_the_scale_exactly():
+    """What lets conv1 take uint8 frames (dvsg_stabilize_ring_u8): for EVERY byte value v, the pixel the reference
+    feeds is x = float32(v / 255.) (eval.py:80: float64 quotient, cast on feed) and scale_RGB's first op gives
+    float32(x * 255) == v exactly (networks.py:8), so the scaled input is float(v) - mean.  And a correctly rounded
+    float32 division v / 255 equals the rounded float64 quotient (no double-rounding case among the 256 values): that
+    is what the warp's uint8 tap loads compute."""
+    v = np.arange(256)
+    x = (v / 255.).astype(np.float32)
+    assert np.array_equal(x * np.float32(255.0), v.astype(np.float32))
+    assert np.array_equal(v.astype(np.float32) / np.float32(255.0), x)
