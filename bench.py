@@ -166,6 +166,36 @@ def cpu_baseline_flow(H, W, budget_s=10.0):
             "sample": "%d single-frame (%dx%d) passes of the NumPy tf_warp oracle; median" % (len(times), W, H)}
 
 
+CNN_GFLOP_PER_FRAME = {(720, 1280): 154.5, (288, 512): 24.6}
+
+
+def latency_mode(net, dev, sizes=((720, 1280), (288, 512)), n_frames=48):
+    """The reference's actual operating point (eval.py:93-124, config.py:12-13,123): ONE clip, batch 1, every frame's
+    window reading the stabilised frames before it -- a lag-1 recurrence, nothing to batch.  `clip.stabilize_clip` on a
+    synthetic float32 clip resident in HBM (one dvsg_stabilize_ring_f32 call per frame), steady state after a 4-frame
+    warm-up clip; 720p and the reference's own 512x288.  Outside the timed region of the line of record."""
+    from coupe.dvsg_amd.clip import stabilize_clip
+    from coupe.dvsg_amd.model import StabNet
+    out = {"mode": "eval.py clip loop: batch 1, exact autoregressive history, clip resident in HBM, float32",
+           "frames_per_clip": n_frames}
+    for H, W in sizes:
+        model = StabNet(H, W)
+        model.locnet = net
+        frames = gpu_windows(n_frames, H, W, 4321, dev, S=1)
+        stabilize_clip(model, None, frames[:4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stab = stabilize_clip(model, None, frames)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_frames
+        assert stab.shape == frames.shape
+        out["%dx%d" % (W, H)] = {"ms_per_frame": 1e3 * dt, "frames_per_s": 1.0 / dt,
+                                 "achieved_tflops": CNN_GFLOP_PER_FRAME[(H, W)] / dt / 1e3,
+                                 "frac_of_f32_mfma_peak": CNN_GFLOP_PER_FRAME[(H, W)] / dt / 1e3 / PEAK_F32_MFMA_TFLOPS}
+        del frames, stab
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS
     process, which never touches the GPU itself (no exec of a GPU-initialised process, no HIP call
@@ -245,6 +275,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32s measurement reported beside the f32 line")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 clip-loop measurement reported beside the line")
     ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f16"],
                     help="f32 (default, the reference's arithmetic: the headline number); f32s: float32 storage / "
                          "accumulation with products from two float16 pieces per operand (dtype f32x2f16); f16: float16 "
@@ -276,8 +307,26 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        # "nccl" is RCCL on ROCm; rendezvous comes from the launcher's MASTER_ADDR / MASTER_PORT
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; rendezvous comes from the launcher's MASTER_ADDR / MASTER_PORT.  A rank that cannot join
+        # (ncclSystemError, rendezvous timeout) says who and where it is and exits non-zero: self_launch / torchrun then
+        # stop the others.  Nothing is retried in this process -- it has touched the GPU.
+        import datetime
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get("DVSG_BENCH_INIT_TIMEOUT_S", "300"))))
+            if backend == "nccl":   # create the communicator now, with every rank present, and fail here if it cannot be
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("communicator sees %d ranks, expected %d" % (int(probe.item()), world))
+        except Exception as exc:   # noqa: BLE001
+            env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                   "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES")}
+            sys.stderr.write("bench.py: rank %d of %d could not join the %s process group on device %d: %s: %s\n  env: %s\n"
+                             % (rank, world, backend, dev_index, type(exc).__name__, exc, env))
+            sys.stderr.flush()
+            raise SystemExit(3)
     on_host = backend != "nccl"
 
     from coupe.dvsg_amd import _lib
@@ -371,9 +420,15 @@ def main():
         ms, n, fl, by = ctypes.c_double(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
         _lib.call("dvsg_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
         prof = (ms.value, n.value, fl.value, by.value)
+    rank_ms = None
     if dist is not None:
+        # the line reports the slowest rank (MAX); the fastest one beside it makes a straggler visible
         t = torch.tensor([elapsed], device="cpu" if on_host else dev, dtype=torch.float64)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_ms = {"min": 1e3 * float(tmin.item()) / args.steps, "max": 1e3 * float(t.item()) / args.steps,
+                   "this_rank": 1e3 * elapsed / args.steps}
         elapsed = float(t.item())
 
     if rank == 0:
@@ -424,6 +479,9 @@ def main():
                        "height": H, "width": W, "parallelism": "window-sharded x%d" % world,
                        "ranks_seen": dist.get_world_size() if dist is not None else 1,
                        "backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version())
+                                        if dist is not None and backend == "nccl" else None),
+                       "ms_per_step_over_ranks": rank_ms,
                        "gather": bool(dist is not None and not args.no_gather), "streams_per_gpu": args.streams,
                        "weights": "n/a" if flow_mode else "synthetic seed 0 (reference ships no checkpoint)"},
             "roofline": roofline,
@@ -448,6 +506,11 @@ def main():
                                              "pieces per operand on the f16 matrix cores; F_t within 2e-7 of the exact path"}
             except Exception as exc:   # noqa: BLE001
                 line["secondary"] = {"precision": "f32s", "error": str(exc)}
+        if world == 1 and not flow_mode and args.precision == "f32" and not args.no_latency:
+            try:
+                line["latency"] = latency_mode(net, dev)
+            except Exception as exc:   # noqa: BLE001
+                line["latency"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_flow(H, W) if flow_mode else cpu_baseline(weights, H, W)
         print(json.dumps(line), flush=True)

@@ -104,3 +104,48 @@ int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes)
   return rc;
 }
 }
+
+// ---- roctx ranges (DVSG_ROCTX=1) ------------------------------------------------------------------------
+#include <dlfcn.h>
+
+#include <cstdlib>
+namespace dvsg {
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char *e = std::getenv("DVSG_ROCTX");
+    if (!e || e[0] == '0' || e[0] == 0) return;
+    // rocprofv3 intercepts the rocprofiler-sdk flavour; the classic libroctx64 serves older tools
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr;
+      pop = nullptr;
+    }
+    std::fprintf(stderr, "dvsg: DVSG_ROCTX is set but no roctx library could be loaded; ranges disabled\n");
+  }
+};
+const Roctx &roctx() {
+  static const Roctx r;   // thread-safe one-time initialisation
+  return r;
+}
+}  // namespace
+
+MarkerRange::MarkerRange(const char *name) : open_(false) {
+  const Roctx &r = roctx();
+  if (r.push) {
+    r.push(name);
+    open_ = true;
+  }
+}
+MarkerRange::~MarkerRange() {
+  if (open_) roctx().pop();
+}
+}  // namespace dvsg
+
+extern "C" int dvsg_markers_enabled(void) { return dvsg::roctx().push != nullptr; }

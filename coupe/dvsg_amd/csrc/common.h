@@ -54,6 +54,21 @@ inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dvsg
 
+// ---- optional roctx ranges (tracing) ------------------------------------------------
+// With DVSG_ROCTX=1 in the environment every stage of the evaluation graph (conv1, pool1, each bottleneck unit, head,
+// tps_solve, tps_warp) opens a roctx range around its launches, so `rocprofv3 --kernel-trace --marker-trace` attributes
+// the kernels of a step to stages and units instead of to kernel names only.  The roctx library is looked up with dlopen
+// at the first range (no link-time dependency); without the variable a range is one relaxed load.
+namespace dvsg {
+struct MarkerRange {
+  explicit MarkerRange(const char *name);
+  ~MarkerRange();
+  MarkerRange(const MarkerRange &) = delete;
+  MarkerRange &operator=(const MarkerRange &) = delete;
+  bool open_;
+};
+}  // namespace dvsg
+
 // ---- optional per-kernel-class timing (bench.py roofline leg; see dvsg_prof_begin) ----------
 namespace dvsg {
 enum KernelClass {

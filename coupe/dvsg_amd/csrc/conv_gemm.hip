@@ -712,6 +712,10 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   d.mt_fast = d.ntiles > 1 && (size_t)(wide ? 128 : 64) * d.K * elem_size(p.prec) >= ((size_t)2 << 20);
   // float16 mode: a launch of several rounds of tiles runs in the 256 x 128 / 64-byte-stage geometry (conv_gemm_wide16.hip)
   if (split && g_conv_variant != 5 && (long)((M + 255) / 256) * (p.Cout / 64) >= g_wide16_min_tiles) return launch_conv_wide16(p, s);
+  // ... and so does a plain-float16 layer (no lo piece: locnet.hip's pair policy) whose 128-channel tiles fill the chip
+  if (p.prec == kF16 && !split && g_conv_variant != 5 && p.Cout % 128 == 0 && p.Cin % 64 == 0 &&
+      (long)((M + 255) / 256) * (p.Cout / 128) >= g_wide16_min_tiles)
+    return launch_conv_wide16(p, s);
   d.ksplit = 1;
   d.slabs = static_cast<float *>(p.splitk_scratch);
   d.counters = p.splitk_counters;

@@ -43,7 +43,10 @@ struct ConvWide16Dev {
   int M, K, mtiles, ntiles;
 };
 
-template <int KS, bool RELU, int RES>
+// SPLIT = false: the 128 weight rows of a tile are 128 output channels of a PLAIN float16 weight matrix [Cout][K] (layers
+// whose weights do not need the lo piece -- locnet.hip's pair policy): the "lo" accumulators are simply the tile's second
+// 64 channels, same loop, half the bytes and MFMAs per output channel.
+template <int KS, bool RELU, int RES, bool SPLIT = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void conv_wide16_kernel(ConvWide16Dev p) {
   constexpr int NW = 8, MI = 2;
@@ -167,10 +170,14 @@ void conv_wide16_kernel(ConvWide16Dev p) {
   __syncthreads();
   compute_stage((KT - 1) & 1);
 
-  // ---- epilogue: 64 output channels, two rounds of 128 pixels through a [128][64] float32 transpose
+  // ---- epilogue: 64 output channels at a time, rounds of 128 pixels through a [128][64] float32 transpose
+  // (SPLIT: one channel half, hi + 2^-11 lo; plain: two channel halves, the accumulators as they are)
   float *Cs = reinterpret_cast<float *>(lds);
   const int col4 = tid & 15, row0 = tid >> 4;   // 16 float4 per row, 32 rows per pass
-  const int n = nt * 64 + 4 * col4;
+  constexpr int NHALF = SPLIT ? 1 : 2;
+#pragma unroll
+  for (int ch = 0; ch < NHALF; ++ch) {
+  const int n = nt * (SPLIT ? 64 : 128) + 64 * ch + 4 * col4;
   const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
 #pragma unroll
   for (int rho = 0; rho < 2; ++rho) {
@@ -202,7 +209,7 @@ void conv_wide16_kernel(ConvWide16Dev p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
           Cs[((wm & 1) * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 64 + wn * 32 + r] =
-              acc_hi[mi][q] + acc_lo[mi][q] * kLoScale;
+              SPLIT ? acc_hi[mi][q] + acc_lo[mi][q] * kLoScale : (ch == 0 ? acc_hi[mi][q] : acc_lo[mi][q]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -224,12 +231,13 @@ void conv_wide16_kernel(ConvWide16Dev p) {
       }
     }
   }
+  }
 }
 
-template <int KS>
+template <int KS, bool SPLIT>
 int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
   const dim3 grid(d.mtiles * d.ntiles), block(512);
-#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_wide16_kernel<KS, R, Q>), grid, block, 0, s, d)
+#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_wide16_kernel<KS, R, Q, SPLIT>), grid, block, 0, s, d)
   if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
@@ -245,7 +253,8 @@ int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
 
 }  // namespace
 
-// p: a float16 layer with stacked weights (p.wsplit), Cin % 64 == 0, Cout % 64 == 0; the caller has opened the ProfScope
+// p: a float16 layer -- stacked [hi | lo] weights (p.wsplit, Cout % 64 == 0) or plain ones (Cout % 128 == 0) -- with
+// Cin % 64 == 0; the caller has opened the ProfScope
 int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
   const long M = (long)p.B * p.Ho * p.Wo;
   ConvWide16Dev d;
@@ -257,9 +266,11 @@ int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
   d.M = (int)M;
   d.K = p.ksize * p.ksize * p.Cin;
   d.mtiles = (int)((M + WBM - 1) / WBM);
-  d.ntiles = p.Cout / 64;
+  d.ntiles = p.wsplit ? p.Cout / 64 : p.Cout / 128;
   const int res = !p.res ? 0 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
-  return p.ksize == 3 ? launch_ks<3>(d, p.relu != 0, res, s) : launch_ks<1>(d, p.relu != 0, res, s);
+  if (p.wsplit) return p.ksize == 3 ? launch_ks<3, true>(d, p.relu != 0, res, s) : launch_ks<1, true>(d, p.relu != 0, res, s);
+  DVSG_REQUIRE(p.Cout % 128 == 0, "conv_wide16: plain weights need Cout %% 128 == 0, got %d", p.Cout);
+  return p.ksize == 3 ? launch_ks<3, false>(d, p.relu != 0, res, s) : launch_ks<1, false>(d, p.relu != 0, res, s);
 }
 
 }  // namespace dvsg

@@ -42,6 +42,7 @@ struct ConvLayer {
 };
 
 struct Unit {
+  int block;   // 0..3
   int base, depth, stride;
   bool has_shortcut;
   ConvLayer shortcut, c1, c2, c3;
@@ -226,6 +227,14 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // float16 precision: conv weights as hi / lo float16 pairs (default) or plain float16 (A/B only:
 // dvsg_debug_set_option("f16_split", 0); 9/10 of the plain mode's F_t error is the weights' rounding)
 int g_f16_split = 1;
+// Which layers of the float16 mode carry the lo piece: bit 4 * kind + block (kind 0 = a unit's conv1, 1 = conv2, 2 = conv3,
+// 3 = shortcut; block 0..3).  A plain float16 weight is off by up to 2^-12 relative at every pixel alike, an error the global
+// average pool does not average away; how much of it reaches F_t depends on the layer (tools/f16_pair_sweep.py measures
+// every block x kind).  A layer without the lo piece runs half the MFMAs and, in the big launches, 128 channels per tile.
+// dvsg_debug_set_option("f16_pair_mask", m): A/B.
+int g_f16_pair_mask = 0xFFFF;
+enum LayerKind { kKindC1 = 0, kKindC2 = 1, kKindC3 = 2, kKindSc = 3 };
+inline bool f16_pairs(int block, int kind) { return g_f16_split && ((g_f16_pair_mask >> (4 * kind + block)) & 1); }
 // block 1's shortcut conv inside the fused conv2 + conv3 kernel (dvsg_debug_set_option("fuse_shortcut", 0): A/B)
 int g_fuse_shortcut = 1;
 
@@ -282,7 +291,7 @@ Workspace plan(char *base, int B, int H, int W) {
   return w;
 }
 
-int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, void *y, int Ho, int Wo,
+int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int H, int W, void *y, int Ho, int Wo,
              const void *res, int res_H, int res_W, int res_stride, bool relu, const Workspace &ws, int *launch_idx,
              hipStream_t s) {
   ConvGemm p;
@@ -290,7 +299,7 @@ int run_conv(int prec, const ConvLayer &L, const void *x, int B, int H, int W, v
   p.splitk_scratch_bytes = kSplitKSlabBytes;
   p.splitk_counters = ws.splitk_counters + (size_t)((*launch_idx)++ % kMaxConvLaunches) * kSplitKMaxTiles;
   p.prec = prec == kF32S ? kF32 : prec;
-  p.wsplit = prec == kF32S || (prec == kF16 && g_f16_split);
+  p.wsplit = prec == kF32S || (prec == kF16 && pairs);
   p.x = x; p.wt = L.weights(prec, p.wsplit != 0); p.bias = L.bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
@@ -342,30 +351,45 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
   DVSG_RUN(launch_zero_tickets(ws.splitk_counters, (size_t)kMaxConvLaunches * kSplitKMaxTiles, s));
   int launch_idx = 0;
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
+  {
+  MarkerRange mr("dvsg/conv1");
   DVSG_RUN(launch_conv1(prec, src, src_kind, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s, net->conv1.bias, ws.bufA, B,
                         H, W, d.H1, d.W1, s));
+  }
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
+  {
+  MarkerRange mr("dvsg/pool1");
   DVSG_RUN(launch_maxpool(prec, ws.bufA, ws.bufB, B, d.H1, d.W1, 64, d.Hp, d.Wp, d.pad_top, d.pad_left, s));
+  }
   DVSG_TAP(1, ws.bufB, d.Hp, d.Wp, 64);
 
   char *X = ws.bufB, *Y = ws.bufA;
   int h = d.Hp, w = d.Wp;
   int stage = 2;
+  int unit_in_block = 0, last_block = -1;
   for (const Unit &u : net->units) {
+    unit_in_block = u.block == last_block ? unit_in_block + 1 : 1;
+    last_block = u.block;
+    char range_name[40];
+    std::snprintf(range_name, sizeof(range_name), "dvsg/block%d/unit_%d", u.block + 1, unit_in_block);
+    MarkerRange mr(range_name);
     const int ho = (h - 1) / u.stride + 1, wo = (w - 1) / u.stride + 1;
     const void *res = X;
     int res_h = h, res_w = w, res_stride = u.stride;
     // (float16 mode: the fused kernel multiplies against the stacked hi / lo weights only)
-    const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) && (prec != kF16 || g_f16_split);
+    const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) &&
+                        (prec != kF16 || (f16_pairs(u.block, kKindC2) && f16_pairs(u.block, kKindC3) &&
+                                          (!u.has_shortcut || f16_pairs(u.block, kKindSc))));
     // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
     const bool fuse_sc = fuse23 && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
                          g_fuse_shortcut;
     if (u.has_shortcut && !fuse_sc) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
-      DVSG_RUN(run_conv(prec, u.shortcut, X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws, &launch_idx, s));
+      DVSG_RUN(run_conv(prec, u.shortcut, f16_pairs(u.block, kKindSc), X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws,
+                        &launch_idx, s));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
     }
-    DVSG_RUN(run_conv(prec, u.c1, X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+    DVSG_RUN(run_conv(prec, u.c1, f16_pairs(u.block, kKindC1), X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
     if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
       const bool pcs = prec == kF32S;
@@ -385,8 +409,10 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       }
       DVSG_RUN(launch_conv3x3_1x1(f, s));
     } else {
-      DVSG_RUN(run_conv(prec, u.c2, ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
-      DVSG_RUN(run_conv(prec, u.c3, ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true, ws, &launch_idx, s));
+      DVSG_RUN(run_conv(prec, u.c2, f16_pairs(u.block, kKindC2), ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
+                        &launch_idx, s));
+      DVSG_RUN(run_conv(prec, u.c3, f16_pairs(u.block, kKindC3), ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true,
+                        ws, &launch_idx, s));
     }
     h = ho; w = wo;
     DVSG_TAP(stage, Y, h, w, u.depth);
@@ -396,6 +422,7 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
 
   // global average pool (float32 partial sums), then the float32 dense head in chunks of <= 16
   // samples; partial layouts are [b][split][k] so a batch chunk is a pointer offset.
+  MarkerRange mr_head("dvsg/head");
   DVSG_RUN(launch_avgpool_partial(prec, X, ws.pool_part, B, h * w, 2048, s));
   const float inv_hw = 1.0f / (float)(h * w);
   if (stop_stage == 18) {
@@ -441,6 +468,7 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
                        as_stream(stream)))
     return rc;
   // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111); float32
+  MarkerRange mr("dvsg/tps");
   if (int rc = tps_apply_impl(net->winv, net->v_src, F, 1, B, 25, ws.T, stream)) return rc;
   return tps_warp_impl(u_t, net->v_src, 0, ws.T, B, H, W, 3, 25, H, W, s_t_pred, x_s, y_s, stream);
 }
@@ -463,6 +491,7 @@ int stabilize_ring(const dvsg_locnet *net, int prec, const void *pool, int pool_
   if (int rc = forward(net, prec, src, pool_is_u8 ? kSrcRingU8 : kSrcRingF32, B, H, W, F, -1, nullptr, 0, nullptr, workspace,
                        workspace_bytes, as_stream(stream)))
     return rc;
+  MarkerRange mr("dvsg/tps");
   if (int rc = tps_apply_impl(net->winv, net->v_src, F, 1, B, 25, ws.T, stream)) return rc;
   return tps_warp_ring_impl(pool, pool_is_u8, n_pool, table + 6, 7, net->v_src, 0, ws.T, B, H, W, 25, s_t_pred, x_s, y_s,
                             stream);
@@ -535,6 +564,7 @@ int dvsg_locnet_create(int n_arrays, const char *const *names, const float *cons
   for (const BlockSpec &bs : kBlocks) {
     for (int u = 1; u <= bs.units; ++u) {
       Unit unit;
+      unit.block = (int)(&bs - kBlocks);
       unit.base = bs.base;
       unit.depth = bs.base * 4;
       unit.stride = u == bs.units ? bs.last_stride : 1;
@@ -726,6 +756,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "f16_split") == 0) {
     g_f16_split = value != 0;
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "f16_pair_mask") == 0) {
+    g_f16_pair_mask = value & 0xFFFF;
     return DVSG_OK;
   }
   return fail(DVSG_ERR_INVALID_ARG, "dvsg_debug_set_option: unknown option %s", name);

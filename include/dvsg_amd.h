@@ -335,6 +335,10 @@ int dvsg_debug_set_option(const char *name, int value);
  * 8 block 1's fused conv2 + conv3.
  * Process-global and not thread-safe: arm it only around single-threaded benchmark code.
  * ------------------------------------------------------------------------------------- */
+/* 1 if DVSG_ROCTX=1 was set when the library first looked and a roctx library could be loaded: every stage of the
+ * evaluation graph (dvsg/conv1, dvsg/pool1, dvsg/block<b>/unit_<u>, dvsg/head, dvsg/tps) then opens a roctx range
+ * around its launches, for `rocprofv3 --kernel-trace --marker-trace` (tracing). */
+int dvsg_markers_enabled(void);
 int dvsg_prof_begin(int kernel_class);
 int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes);
 

@@ -131,3 +131,16 @@ def test_c_demo_runs_the_known_answer_tests(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "all checks passed" in out.stdout
+
+
+def test_roctx_ranges_are_off_by_default_and_load_on_request():
+    """DVSG_ROCTX=1 makes every stage / bottleneck unit open a roctx range; the roctx
+    library is found with dlopen at run time and the switch is read once per process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from coupe.dvsg_amd import _lib; "
+            "print(_lib.load().dvsg_markers_enabled())" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "DVSG_ROCTX"}
+    off = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+    on = subprocess.run([sys.executable, "-c", code], env=dict(env, DVSG_ROCTX="1"), capture_output=True, text=True, check=True)
+    assert off.stdout.strip() == "0" and on.stdout.strip() == "1", (off.stdout, on.stdout, on.stderr)

@@ -36,6 +36,12 @@ def test_bench_line_has_the_contract_fields():
     assert c["cpu_model"] and c["cnn_ms_per_frame"] > 0 and c["warp_ms_per_frame"] > 0
     s2 = d["secondary"]      # the f32s rate, beside the line of record and outside its timed region
     assert s2["precision"] == "f32s" and s2["dtype"] == "f32x2f16" and s2["value"] > 0
+    # the reference's own operating point -- eval.py's batch-1 autoregressive clip loop -- beside the line, with a bound
+    # that catches a regression of the per-frame path (measured on MI355X, round 3: 2.14 ms at 720p, 1.11 ms at 512x288)
+    lat = d["latency"]
+    assert "error" not in lat, lat
+    assert 0 < lat["1280x720"]["ms_per_frame"] < 3.0 and 0 < lat["512x288"]["ms_per_frame"] < 1.6
+    assert abs(lat["1280x720"]["achieved_tflops"] - 154.5 / lat["1280x720"]["ms_per_frame"]) < 1e-6
 
 
 def test_bench_other_kernel_classes_and_precision():
@@ -65,6 +71,9 @@ def test_bench_rccl_calls_of_the_sharded_path_run_on_one_rank():
     c = d["config"]
     assert c["backend"] == "rccl" and c["gather"] is True and c["ranks_seen"] == 1
     assert c["windows_per_step"] == 4 and c["windows_per_call"] == 2 and d["value"] > 0
+    assert c["rccl_version"] and c["rccl_version"][0].isdigit()
+    r = c["ms_per_step_over_ranks"]       # slowest / fastest rank: a straggler shows as min << max
+    assert 0 < r["min"] <= r["max"] and abs(r["max"] - d["ms_per_step"]) < 1e-9
 
 
 def test_bench_self_launches_its_ranks():
@@ -96,4 +105,21 @@ def test_bench_self_launch_reports_a_failing_rank():
                           "--batch", "2", "--height", "64", "--width", "96"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_that_cannot_join_exits_with_its_identity():
+    """A rank whose peers never arrive (or whose RCCL initialisation fails) must say who and where it is and exit
+    non-zero instead of hanging: WORLD_SIZE=2 with only rank 0 started, 5 s rendezvous timeout."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               DVSG_BENCH_BACKEND="gloo", DVSG_BENCH_SHARE_DEVICE="1", DVSG_BENCH_INIT_TIMEOUT_S="5")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "2", "--height", "64", "--width", "96"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert "rank 0 of 2 could not join" in out.stderr and "MASTER_PORT" in out.stderr
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
