@@ -80,6 +80,16 @@ class StabNet:
     def load_ckpt(self, ckpt_dir, by_score=True):
         return self.load_weights(_weights.load_ckpt_dir(ckpt_dir, by_score))
 
+    def init_vars(self, weights, ckpt_path='./pretrained/resnet_v1_50.ckpt', sess=None):
+        """model.py:125-154: the trainer's ImageNet initialisation, for evaluation-only users.  `weights` (a dict in the
+        reference's variable naming, e.g. a `.npz` of ckpt_manager.py or `make_synthetic_weights`) supplies what the
+        slim checkpoint does not hold or must not overwrite -- the 21-channel root `conv1` (excluded, :126) and the
+        tensorlayer dense head -- and every other `resnet_v1_50/...` array is read from the TensorFlow checkpoint at
+        `ckpt_path` (V1 single file or V2 bundle prefix; read without TensorFlow by `tf_checkpoint`, parity unpinned).
+        `sess` is accepted for call-site symmetry and not used."""
+        from .tf_checkpoint import init_from_slim_checkpoint
+        return self.load_weights(init_from_slim_checkpoint(weights, ckpt_path, model=self.stabNet_model))
+
     # -- graph (model.py:98-123) ------------------------------------------------------------
     def get_evaluation_model(self, sample_num):
         self.sample_num = sample_num
