@@ -2,6 +2,7 @@
 // `max_pool2d(3x3, stride 2, SAME)`) with scale_RGB (networks.py:6-16) fused into conv1's
 // load stage.
 #include <cstdint>
+#include <type_traits>
 
 #include "cnn_device.h"
 #include "cnn_kernels.h"
@@ -52,11 +53,16 @@ template <int NT, int GROUPS, bool ALIGNED>
 struct Conv1Row {
   static constexpr bool kRing = false;
   typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
-  float mean[4 * GROUPS];
+  floatx4 nmean[GROUPS];   // minus the channel-group mean of each element: x * 255 + (-mean) == x * 255 - mean exactly
   long idx[GROUPS];
   unsigned col_ok, full;
-  floatx4 reg[GROUPS];   // the row in flight (prefetched under the previous kernel row's MFMAs)
-  bool row_ok;
+  bool fast;               // wave-uniform: every element this wave stages lies inside the image row (or behind the segment's
+                           // end, where the weights are zero): no per-element masks -- packed multiply / add / f16 convert,
+                           // 1.5 VALU per element where the masked path spends ~7 (SQ_INSTS_VALU: 10 per MFMA in the f16 kernel)
+  struct Data {            // one input row in flight (prefetched under the MFMAs of the rows before it)
+    floatx4 reg[GROUPS];
+    bool row_ok;
+  };
   const float *img;      // window b
   long row_elems;
   int H;
@@ -67,7 +73,7 @@ struct Conv1Row {
     img = static_cast<const float *>(src.base) + (long)b * H * row_elems;
     const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
     col_ok = full = 0;
-    row_ok = false;
+    bool mine = true;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       const int e0 = 4 * (tid + NT * i);
@@ -77,38 +83,44 @@ struct Conv1Row {
         const int e = e0 + j;
         const long ge = seg0 + e;
         const int g = ((e + kConv1Cin - 1) % kConv1Cin) / (kConv1Cin / 3);
-        mean[4 * i + j] = g == 0 ? 123.68f : (g == 1 ? 116.779f : 103.939f);
+        nmean[i][j] = g == 0 ? -123.68f : (g == 1 ? -116.779f : -103.939f);
         if (e < seg_elems && ge >= 0 && ge < row_elems) m |= 1u << j;
+        if (e < seg_elems && !(ge >= 0 && ge < row_elems)) mine = false;   // a pad column this thread must zero
       }
       col_ok |= m << (4 * i);
       if (m == 15u) full |= 1u << i;
       idx[i] = (ALIGNED && m != 15u) ? 0 : seg0 + e0;   // ALIGNED: a group outside the row reads the row's first
     }
+    // (elements behind the segment's end are staged as whatever finite value the clamped load returned: they meet zero weights)
+    fast = ALIGNED && __builtin_amdgcn_ballot_w64(!mine) == 0;
   }
-  // input row 2 ho + kh - 3 (clamped into the image; `row_ok` remembers whether it was inside)
-  __device__ __forceinline__ void load(int ho, int kh) {
-    const int hi = 2 * ho + kh - 3;
-    row_ok = hi >= 0 && hi < H;
+  // input row `hi` (clamped into the image; `row_ok` remembers whether it was inside)
+  __device__ __forceinline__ void load(Data &d, int hi) const {
+    d.row_ok = hi >= 0 && hi < H;
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = img + (long)hc * row_elems;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       if constexpr (ALIGNED) {
-        reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx[i]);
+        d.reg[i] = *reinterpret_cast<const floatx4 *>(xrow + idx[i]);
       } else if ((full >> i) & 1u) {
-        reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx[i]);
+        d.reg[i] = *reinterpret_cast<const floatx4_u *>(xrow + idx[i]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx[i] + j] : 0.f;
+        for (int j = 0; j < 4; ++j) d.reg[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? xrow[idx[i] + j] : 0.f;
       }
     }
   }
-  // group i of the row in flight, scaled
-  __device__ __forceinline__ floatx4 scaled(int i) const {
-    const unsigned ok = row_ok ? col_ok : 0u;
+  // group i of a row in flight, scaled
+  __device__ __forceinline__ floatx4 scaled(const Data &d, int i) const {
+    if (fast) {   // (both conditions are uniform over the wave / the workgroup)
+      if (!d.row_ok) return floatx4{0.f, 0.f, 0.f, 0.f};
+      return d.reg[i] * 255.0f + nmean[i];
+    }
+    const unsigned ok = d.row_ok ? col_ok : 0u;
     floatx4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? reg[i][j] * 255.0f - mean[4 * i + j] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? d.reg[i][j] * 255.0f + nmean[i][j] : 0.f;
     return v;
   }
 };
@@ -140,15 +152,18 @@ struct Conv1RingRow {
   static_assert(NT * GROUPS >= C1_RING_GROUPS, "not enough threads x groups for 7 frame runs");
   static_assert(GROUPS <= 8, "per-element masks are 32 bits wide");
   typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
-  float mean[4 * GROUPS];
+  floatx4 nmean[GROUPS];   // minus the channel-group mean of each element
+  bool fast;               // wave-uniform: no pad column and no missing frame among this wave's elements (see Conv1Row)
   long off[GROUPS];        // element offset of the group in the pool, row 0 of its frame
   int l0[GROUPS];          // LDS element of the first value's PIXEL (channel 3 f of it)
   unsigned phase;          // 2 bits per group: rgb of the group's first value
   unsigned col_ok, st_ok;  // per element: inside the image row / inside the staged segment
   unsigned no_frame;       // per group: its window slot names a frame outside the pool (reads as a frame of zeros)
-  floatx4 regf[kU8 ? 1 : GROUPS];
-  unsigned regu[kU8 ? GROUPS : 1];
-  bool row_ok;
+  struct Data {            // one input row in flight
+    floatx4 regf[kU8 ? 1 : GROUPS];
+    unsigned regu[kU8 ? GROUPS : 1];
+    bool row_ok;
+  };
   const TS *pool;
   long row_elems;
   int H;
@@ -160,7 +175,7 @@ struct Conv1RingRow {
     const long frame_elems = (long)H * row_elems;
     const long r_first = (long)(2 * wo0 - 4) * 3;    // one pixel before the segment: a multiple of 4
     col_ok = st_ok = phase = no_frame = 0;
-    row_ok = false;
+    bool mine = true;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       const int q = tid + NT * i;
@@ -175,11 +190,12 @@ struct Conv1RingRow {
         const int t = 4 * g + j;                      // element of the run, lead-in pixel included
         const int c = 3 * f + t % 3;
         const int grp = c / (kConv1Cin / 3);
-        mean[4 * i + j] = grp == 0 ? 123.68f : (grp == 1 ? 116.779f : 103.939f);
+        nmean[i][j] = grp == 0 ? -123.68f : (grp == 1 ? -116.779f : -103.939f);
         if (in_range && t >= 3 && t < 3 * (C1_RING_PX + 1)) ms |= 1u << j;
         if (in_range && r0 + j >= 0 && r0 + j < row_elems) mc |= 1u << j;
       }
       if (in_range && !frame_ok) no_frame |= 1u << i;   // raw value 0 (scaled: -mean), read from the pool's frame 0 and dropped
+      if ((ms & ~mc) != 0 || (in_range && !frame_ok)) mine = false;
       // ALIGNED: a group lies inside the row or outside it as a whole (both ends of the row and the run's start are
       // multiples of four elements); outside it reads row `hc` of the pool's first frame and its values are dropped.
       // Element-wise otherwise.
@@ -193,10 +209,10 @@ struct Conv1RingRow {
       l0[i] = 1 + kConv1Cin * ((4 * g) / 3 - 1) + 3 * f;
       phase |= (unsigned)((4 * g) % 3) << (2 * i);
     }
+    fast = __builtin_amdgcn_ballot_w64(!mine) == 0;
   }
-  __device__ __forceinline__ void load(int ho, int kh) {
-    const int hi = 2 * ho + kh - 3;
-    row_ok = hi >= 0 && hi < H;
+  __device__ __forceinline__ void load(Data &d, int hi) const {
+    d.row_ok = hi >= 0 && hi < H;
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const long roff = (long)hc * row_elems;
 #pragma unroll
@@ -204,40 +220,51 @@ struct Conv1RingRow {
       const TS *p = pool + off[i] + roff;
       if constexpr (kU8) {
         if constexpr (ALIGNED) {
-          regu[i] = *reinterpret_cast<const unsigned *>(p);
+          d.regu[i] = *reinterpret_cast<const unsigned *>(p);
         } else {
           unsigned w = 0;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if ((col_ok >> (4 * i + j)) & 1u) w |= (unsigned)p[j] << (8 * j);
-          regu[i] = w;
+          d.regu[i] = w;
         }
       } else {
         if constexpr (ALIGNED) {
-          regf[i] = *reinterpret_cast<const floatx4 *>(p);
+          d.regf[i] = *reinterpret_cast<const floatx4 *>(p);
         } else if (((col_ok >> (4 * i)) & 15u) == 15u) {
-          regf[i] = *reinterpret_cast<const floatx4_u *>(p);
+          d.regf[i] = *reinterpret_cast<const floatx4_u *>(p);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) regf[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? (float)p[j] : 0.f;
+          for (int j = 0; j < 4; ++j) d.regf[i][j] = ((col_ok >> (4 * i + j)) & 1u) ? (float)p[j] : 0.f;
         }
       }
     }
   }
-  // every staged element of the row in flight, scaled: put(LDS element index, value)
+  // every staged element of a row in flight, scaled: put(LDS element index, value)
   template <typename PUT>
-  __device__ __forceinline__ void scatter(PUT put) const {
-    const unsigned ok = row_ok ? col_ok : 0u;
+  __device__ __forceinline__ void scatter(const Data &d, PUT put) const {
+    const unsigned ok = d.row_ok ? col_ok : 0u;
+    const bool plain = fast && d.row_ok;   // uniform: no masks to apply
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       const int ph = (phase >> (2 * i)) & 3u;
+      floatx4 raw4;
+      if constexpr (kU8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw4[j] = (float)((d.regu[i] >> (8 * j)) & 255u);   // == f32(v / 255.) * 255.f, exactly
+      } else {
+        raw4 = d.regf[i] * 255.0f;
+      }
+      const floatx4 sc4 = raw4 + nmean[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float raw;
-        if constexpr (kU8) raw = (float)((regu[i] >> (8 * j)) & 255u);   // == f32(v / 255.) * 255.f, exactly
-        else raw = regf[i][j] * 255.0f;
-        if ((no_frame >> i) & 1u) raw = 0.f;
-        const float v = ((ok >> (4 * i + j)) & 1u) ? raw - mean[4 * i + j] : 0.f;
+        float v;
+        if (plain) {
+          v = sc4[j];
+        } else {
+          const float raw = ((no_frame >> i) & 1u) ? 0.f : raw4[j];
+          v = ((ok >> (4 * i + j)) & 1u) ? raw + nmean[i][j] : 0.f;
+        }
         const int t = ph + j, step = t / 3;                              // t in 0..5
         if ((st_ok >> (4 * i + j)) & 1u) put(l0[i] + kConv1Cin * step + (t - 3 * step), v);
       }
@@ -296,9 +323,10 @@ void conv1_kernel(const Conv1Src src, const float *__restrict__ wt1, const float
   if constexpr (Row::kRing) {   // elements the scatter never writes (the zero tap's slot, the tail) must be finite
     for (int e = tid; e < C1_SEG_PAD; e += NT) in_s[e] = 0.f;
   }
+  typename Row::Data rd;
   floatx4 w_reg[WLOADS];
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
-    row.load(ho, kh);
+    row.load(rd, 2 * ho + kh - 3);
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1 + (size_t)kh * C1_WELEMS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -308,12 +336,12 @@ void conv1_kernel(const Conv1Src src, const float *__restrict__ wt1, const float
   };
   auto store_stage = [&]() __attribute__((always_inline)) {
     if constexpr (Row::kRing) {
-      row.scatter([&](int e, float v) __attribute__((always_inline)) { in_s[e] = v; });
+      row.scatter(rd, [&](int e, float v) __attribute__((always_inline)) { in_s[e] = v; });
     } else {
 #pragma unroll
       for (int i = 0; i < IN4; ++i) {
         const int q = tid + NT * i;
-        const floatx4 v = row.scaled(i);
+        const floatx4 v = row.scaled(rd, i);
         if (q < C1_SEG_PAD / 4) reinterpret_cast<floatx4 *>(in_s)[q] = v;
       }
     }
@@ -547,25 +575,26 @@ void conv1_f16_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h, con
 
   typedef const __attribute__((address_space(1))) void *gptr_t;
   typedef __attribute__((address_space(3))) void *lptr_t;
+  typename Row::Data rd;
   auto load_stage = [&](int kh, int buf) __attribute__((always_inline)) {
     // weights of kernel row kh: 21 pieces of 1 KiB, piece j by wave j % 4, straight into LDS
     const char *wsrc = reinterpret_cast<const char *>(wt1h) + (size_t)kh * C1H_WBYTES;
     for (int j = wave; j < C1H_WBYTES / 1024; j += 4)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024 + lane * 16), (lptr_t)(w_s + buf * C1H_WBYTES + j * 1024),
                                        16, 0, 0);
-    row.load(ho, kh);
+    row.load(rd, 2 * ho + kh - 3);
   };
   auto store_stage = [&](int buf) __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     if constexpr (Row::kRing) {
       _Float16 *dsth = reinterpret_cast<_Float16 *>(in_s + buf * C1H_SEG * 2);
-      row.scatter([&](int e, float v) __attribute__((always_inline)) { dsth[e] = (_Float16)v; });
+      row.scatter(rd, [&](int e, float v) __attribute__((always_inline)) { dsth[e] = (_Float16)v; });
     } else {
       half4_t *dst = reinterpret_cast<half4_t *>(in_s + buf * C1H_SEG * 2);
 #pragma unroll
       for (int i = 0; i < C1H_IN4; ++i) {
         const int q = tid + 256 * i;
-        const floatx4 v = row.scaled(i);   // then one rounding to f16
+        const floatx4 v = row.scaled(rd, i);   // then one rounding to f16
         half4_t hv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
@@ -641,6 +670,193 @@ void conv1_f16_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h, con
 }
 
 // ----------------------------------------------------------------------------------------
+// conv1, float16 precision, TWO output rows per workgroup (rows 2 p and 2 p + 1 of one 128-pixel tile).
+//
+// Why.  rocprofv3 counters of conv1_f16_kernel at 3840x2160, batch 32 (profiles/r02_f16_pmc_sq.csv): matrix pipe busy
+// 27 %, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = 0.44 with two waves per SIMD -- the SIMDs issue instructions 88 % of the time:
+// the kernel is bound by INSTRUCTION ISSUE (and, at 304 KB of L2 -> CU traffic per tile, close to the L2's rate), not by
+// the matrix cores or HBM (FETCH_SIZE = the input once).  Per kernel row and wave it issues ~110 VALU (scale_RGB, the
+// float16 rounding), 60 LDS fragment reads, 11 memory instructions and 20 MFMAs: 11 other instructions per MFMA.
+// Two rows per workgroup attack every term:
+//   * the weights of a kernel row (21.5 KB by LDS-DMA) and their fragment reads serve both rows: per MFMA half the weight
+//     traffic and half the B reads;
+//   * the kernel rows are visited as two chains, kh = 0, 2, 4, 6 and kh = 1, 3, 5.  Within a chain the input row that
+//     output row 2 p + 1 needs at step kh (row a + kh + 2) is the one output row 2 p needs at step kh + 2: it stays where
+//     it is, and only ONE new input row is staged per step -- 9 stagings per pair of output rows instead of 14;
+//   * a step is 40 MFMAs, so the two barriers and the address arithmetic of a step cost half as much per MFMA.
+// Staging as in conv1_kernel: the next step's new row(s) are fetched into registers under this step's MFMAs and, after
+// the barrier that ends the step, scaled, rounded and stored over the row nobody needs any more; the weights of the next
+// step arrive by LDS-DMA in the other weight buffer meanwhile.  LDS: 2 x 21.5 KB of weights + 2 x 11 KB of rows, two
+// workgroups per CU, as before.
+// ----------------------------------------------------------------------------------------
+template <typename TO, int SRC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_f16_pair_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h, const float *__restrict__ bias,
+                           TO *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles, int hpairs) {
+  static_assert(C1_TILE * C1_LDC * 4 <= 2 * C1H_WBYTES, "epilogue tile must fit in the weight stages");
+  __shared__ __attribute__((aligned(16))) char lds[2 * C1H_WBYTES + 2 * C1H_SEG * 2];
+  char *w_s = lds;
+  char *in_s = lds + 2 * C1H_WBYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;   // wave w: pixels [32 w, 32 w + 32) x all 64 channels x both rows
+
+  int blk = xcd_remap(blockIdx.x, gridDim.x);  // see conv1_kernel
+  const int wt_i = blk % wtiles;
+  blk /= wtiles;
+  const int ho0 = 2 * (blk % hpairs);
+  const int b = blk / hpairs;
+  const int wo0 = wt_i * C1_TILE;
+
+  typedef typename Conv1RowSel<256, C1H_IN4, SRC>::type Row;
+  Row row;
+  row.init(src, tid, b, wo0, H, W, C1H_SEG);
+  if constexpr (Row::kRing) {   // both images: the zero tap's slot and the tail are read against zero weights
+    for (int e = tid; e < C1H_SEG; e += 256) reinterpret_cast<unsigned *>(in_s)[e] = 0u;
+  }
+  typename Row::Data d0, d1;
+
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  auto weights_dma = [&](int kh, int wbuf) __attribute__((always_inline)) {
+    const char *wsrc = reinterpret_cast<const char *>(wt1h) + (size_t)kh * C1H_WBYTES;
+    for (int j = wave; j < C1H_WBYTES / 1024; j += 4)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024 + lane * 16), (lptr_t)(w_s + wbuf * C1H_WBYTES + j * 1024),
+                                       16, 0, 0);
+  };
+  auto store_row = [&](const typename Row::Data &d, int buf) __attribute__((always_inline)) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    if constexpr (Row::kRing) {
+      _Float16 *dsth = reinterpret_cast<_Float16 *>(in_s + buf * C1H_SEG * 2);
+      row.scatter(d, [&](int e, float v) __attribute__((always_inline)) { dsth[e] = (_Float16)v; });
+    } else {
+      half4_t *dst = reinterpret_cast<half4_t *>(in_s + buf * C1H_SEG * 2);
+#pragma unroll
+      for (int i = 0; i < C1H_IN4; ++i) {
+        const int q = tid + 256 * i;
+        const floatx4 v = row.scaled(d, i);   // then one rounding to f16
+        half4_t hv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
+        if (q < C1H_SEG / 4) dst[q] = hv;
+      }
+    }
+  };
+
+  floatx16 acc[2][2];   // [output row][channel block]
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][ni][q] = 0.f;
+
+  // input row of (output row ho0 + j, kernel row kh)
+  const int a = 2 * ho0 - 3;
+  // prologue: rows a, a + 2 and the weights of kernel row 0
+  row.load(d0, a);
+  row.load(d1, a + 2);
+  weights_dma(0, 0);
+  store_row(d0, 0);
+  store_row(d1, 1);
+  __syncthreads();
+  int lo = 0;   // buffer of output row ho0's input row; the other one holds output row ho0 + 1's
+  // (seven explicit instances: left to `#pragma unroll` the optimizer gives up on this body and the kernel-row order
+  // becomes a table lookup)
+  auto step = [&](auto S) __attribute__((always_inline)) {
+    constexpr int s = decltype(S)::value;
+    constexpr int kOrder[8] = {0, 2, 4, 6, 1, 3, 5, -1};
+    constexpr int kh = kOrder[s], khn = kOrder[s + 1];
+    constexpr bool chain = khn == kh + 2;        // the next step continues this chain: one new row
+    if (khn >= 0) {
+      row.load(d0, chain ? a + khn + 2 : a + khn);
+      if (!chain) row.load(d1, a + khn + 2);
+      weights_dma(khn, (s + 1) & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned *a0 = reinterpret_cast<const unsigned *>(in_s + lo * C1H_SEG * 2) + kConv1Cin * (wave * 32 + r) + 4 * h;
+    const unsigned *a1 = reinterpret_cast<const unsigned *>(in_s + (lo ^ 1) * C1H_SEG * 2) + kConv1Cin * (wave * 32 + r) + 4 * h;
+    const char *bp = w_s + (s & 1) * C1H_WBYTES + 2 * (r * C1H_LD + 8 * h);
+    struct Frag {
+      union {
+        unsigned u[4];
+        halfx8 v;
+      } a[2];
+      halfx8 b[2];
+    };
+    auto read_frag = [&](Frag &f, int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f.a[0].u[j] = a0[8 * t + j];
+        f.a[1].u[j] = a1[8 * t + j];
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) f.b[ni] = *reinterpret_cast<const halfx8 *>(bp + 2 * ni * 32 * C1H_LD + 32 * t);
+    };
+    Frag fr[2];
+    read_frag(fr[0], 0);
+#pragma unroll
+    for (int t = 0; t < C1H_STEPS; ++t) {
+      if (t + 1 < C1H_STEPS) read_frag(fr[(t + 1) & 1], t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const Frag &f = fr[t & 1];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[j].v, f.b[ni], acc[j][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // everyone has read this step's rows; the prefetched row(s) and the next weights have landed
+    if (khn >= 0) {
+      if (chain) {
+        store_row(d0, lo);   // over the row of output row ho0: the other one becomes its row for the next step
+        lo ^= 1;
+      } else {
+        store_row(d0, lo);
+        store_row(d1, lo ^ 1);
+      }
+      __syncthreads();
+    }
+  };
+  step(std::integral_constant<int, 0>{});
+  step(std::integral_constant<int, 1>{});
+  step(std::integral_constant<int, 2>{});
+  step(std::integral_constant<int, 3>{});
+  step(std::integral_constant<int, 4>{});
+  step(std::integral_constant<int, 5>{});
+  step(std::integral_constant<int, 6>{});
+
+  float *Cs = reinterpret_cast<float *>(lds);
+  const int col4 = tid & 15, row0 = tid >> 4;
+  const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j) __syncthreads();   // the first row's tile has been read
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        Cs[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + ni * 32 + r] = acc[j][ni][q];
+    __syncthreads();
+    if (ho0 + j < Ho) {
+      TO *yrow = y + (((size_t)b * Ho + ho0 + j) * Wo + wo0) * 64 + 4 * col4;
+#pragma unroll 4
+      for (int rw = row0; rw < C1_TILE; rw += 16) {
+        if (wo0 + rw >= Wo) break;
+        float4 v = *reinterpret_cast<const float4 *>(Cs + rw * C1_LDC + 4 * col4);
+        v.x = fmaxf(v.x + b4.x, 0.f);
+        v.y = fmaxf(v.y + b4.y, 0.f);
+        v.z = fmaxf(v.z + b4.z, 0.f);
+        v.w = fmaxf(v.w + b4.w, 0.f);
+        store4(yrow + (size_t)rw * 64, v);
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // conv1 for the "f32s" precision: conv1_kernel's decomposition and staging (one output row x 128 pixels x
 // 64 channels per workgroup, the input row segment prefetched into registers under the previous kernel
 // row's MFMAs, scale_RGB applied while staging, overlapping windows read in place), with the products
@@ -688,9 +904,10 @@ void conv1_split_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1s, c
   if constexpr (Row::kRing) {
     for (int e = tid; e < C1S_SEG / 2; e += NT) in_hi[e] = in_lo[e] = 0u;
   }
+  typename Row::Data rd;
   floatx4 w_reg[WLOADS];
   auto load_stage = [&](int kh) __attribute__((always_inline)) {
-    row.load(ho, kh);
+    row.load(rd, 2 * ho + kh - 3);
     const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1s + (size_t)kh * C1S_WHALFS);
 #pragma unroll
     for (int i = 0; i < WLOADS; ++i) {
@@ -701,7 +918,7 @@ void conv1_split_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1s, c
   auto store_stage = [&]() __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
     if constexpr (Row::kRing) {
-      row.scatter([&](int e, float v) __attribute__((always_inline)) {
+      row.scatter(rd, [&](int e, float v) __attribute__((always_inline)) {
         const _Float16 hv = (_Float16)v;
         reinterpret_cast<_Float16 *>(in_hi)[e] = hv;
         reinterpret_cast<_Float16 *>(in_lo)[e] = (_Float16)(v - (float)hv);
@@ -710,7 +927,7 @@ void conv1_split_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1s, c
 #pragma unroll
       for (int i = 0; i < C1S_IN4; ++i) {
         const int q = tid + NT * i;
-        const floatx4 v = row.scaled(i);   // then the two pieces
+        const floatx4 v = row.scaled(rd, i);   // then the two pieces
         half4_t hv, lv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -877,8 +1094,22 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
   } while (0)
   if (out_prec == kF32S) {
     DVSG_C1(DVSG_K_SPLIT, 256, static_cast<const _Float16 *>(wt1s), static_cast<float *>(y));
-  } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {
+  } else if (out_prec == kF16 && wt1h && g_conv1_variant == 3) {   // A/B: one output row per workgroup
     DVSG_C1(DVSG_K_F16, 256, static_cast<const _Float16 *>(wt1h), static_cast<_Float16 *>(y));
+  } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {   // two output rows per workgroup (conv1_f16_pair_kernel)
+    const int hpairs = (Ho + 1) / 2;
+    const long pblocks = (long)wtiles * hpairs * B;
+    const dim3 pgrid((unsigned)pblocks);
+    const _Float16 *wp = static_cast<const _Float16 *>(wt1h);
+    _Float16 *yp = static_cast<_Float16 *>(y);
+    switch (SRC) {
+      case 0: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 0>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 1: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 1>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 2: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 2>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 3: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 3>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 4: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 4>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      default: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 5>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+    }
   } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output (window tensors only)
     DVSG_REQUIRE(src_kind == kSrcWindow, "conv1: conv1_variant 2 takes a window tensor");
     hipLaunchKernelGGL((conv1_kernel<4, _Float16, 0>), grid, dim3(256), 0, s, src, wt1, bias, static_cast<_Float16 *>(y), H, W,
