@@ -857,6 +857,360 @@ void conv1_f16_pair_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h
 }
 
 // ----------------------------------------------------------------------------------------
+// conv1, float16 precision, for the big launches: a workgroup MARCHES down a band of output rows of one 128-pixel
+// column tile, four output rows ("quad") at a time, and its eight waves are SPECIALISED --
+//
+//   waves 0-3  multiply: pixels [32 w, 32 w + 32) x 64 channels x the quad's 4 rows (128 accumulator registers);
+//              their instruction stream is fragment reads + MFMAs only (80 MFMAs per step);
+//   waves 4-7  stage: fetch the input rows the NEXT step needs, scale_RGB them, round to float16, store them in LDS,
+//              and start the LDS-DMA of the next step's weight row.
+//
+// A wave of each kind shares a SIMD, so the staging arithmetic issues in the shadow of the matrix pipe instead of
+// between its MFMAs: conv1_f16_pair_kernel was bound by instruction ISSUE (SQ_ACTIVE_INST_ANY = 0.34 of the wave cycles
+// with two waves per SIMD, 6.8 VALU + 1.9 LDS + 3 scalar instructions per MFMA, matrix pipe busy 35 %).
+//
+// Marching makes the staged rows a SLIDING WINDOW.  A step is one kernel row kh for the quad's four output rows
+// r0 .. r0 + 3, which need the input rows a + kh + {0, 2, 4, 6} (a = 2 r0 - 3).  The steps of a quad run as two chains,
+// kh = 0, 2, 4, 6 and kh = 1, 3, 5; a chain's window moves up by one input row of its parity per step and -- because the
+// next quad starts 8 input rows further down -- continues seamlessly from quad to quad.  So every input row is staged
+// ONCE per column tile (8 stagings per quad = 2 per output row; the one-row kernel staged 7, the pair kernel 4.5), into
+// one of two rings of five row buffers (odd and even input rows): four rows of the current window + the one being
+// filled.  The weights of a kernel row serve four output rows (a quarter of the weight traffic and B-fragment reads per
+// MFMA of the one-row kernel).  One barrier per step is the only synchronisation: what step s + 1 needs is staged during
+// step s.
+//
+// The MFMA operands are swapped against the other conv1 kernels (A = weights, B = pixels), so a lane ends up with 16
+// CHANNELS of one pixel: bias, ReLU, the float16 rounding and 8-byte stores happen from the accumulators, with no LDS
+// transpose (there is no LDS left for one: 10 x 11 KB of rows + 2 x 21.5 KB of weights = 153 KB, one workgroup per CU).
+// Used when the launch gives every CU several bands (launch_conv1); small launches keep conv1_f16_pair_kernel.
+// ----------------------------------------------------------------------------------------
+constexpr int C1M_QUAD = 4;                         // output rows per quad
+constexpr int C1M_RING = 5;                         // row buffers per parity
+constexpr int C1M_LDS = 2 * C1M_RING * C1H_SEG * 2 + 2 * C1H_WBYTES;   // 153 088 bytes
+
+template <int SRC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_f16_march_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h, const float *__restrict__ bias,
+                            _Float16 *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles, int bands, int quads_per_band) {
+  __shared__ __attribute__((aligned(16))) char lds[C1M_LDS];
+  char *w_s = lds;                                   // [2][C1H_WBYTES]
+  char *in_s = lds + 2 * C1H_WBYTES;                 // [2 parities][C1M_RING][C1H_SEG halves]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool stager = wave >= 4;
+  const int r = lane & 31, h = lane >> 5;
+
+  int blk = xcd_remap(blockIdx.x, gridDim.x);        // an XCD takes neighbouring column tiles / bands of one image
+  const int wt_i = blk % wtiles;
+  blk /= wtiles;
+  const int band = blk % bands;
+  const int b = blk / bands;
+  const int wo0 = wt_i * C1_TILE;
+  const int rb0 = band * quads_per_band * C1M_QUAD;                       // first output row of the band
+  const int nq = min(quads_per_band, (Ho - rb0 + C1M_QUAD - 1) / C1M_QUAD);
+  const int nsteps = 7 * nq;
+  // step s: quad s / 7, kernel row kOrder[s % 7]; its window of input rows starts at 2 (rb0 + 4 quad) - 3 + kh
+  auto window_of = [&](int s) __attribute__((always_inline)) -> int {
+    const int quad = s / 7, ks = s - 7 * quad;
+    const int kh = ks < 4 ? 2 * ks : 2 * ks - 7;
+    return 2 * (rb0 + C1M_QUAD * quad) - 3 + kh;
+  };
+  // ring slot (in halves from in_s) of input row `row`: odd rows (the even-kh chain) in the first ring
+  auto slot_of = [&](int row) __attribute__((always_inline)) -> int {
+    const int u = (row + 64) >> 1;                   // rows >= -3: non-negative
+    return (((row & 1) ? 0 : C1M_RING) + u % C1M_RING) * C1H_SEG;
+  };
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  if (stager) {
+    // ------------------------------------------------------------------------------ staging waves
+    // (their few instructions go first when both waves of a SIMD are ready: with the default oldest-first arbitration the
+    // staging wave -- the younger one -- only issued while the multiplying wave was stalled: stamps, tools/stamp_probe_march.py)
+    __builtin_amdgcn_s_setprio(3);
+    const int st = tid - 256;
+    typedef typename Conv1RowSel<256, C1H_IN4, SRC>::type Row;
+    Row row;
+    row.init(src, st, b, wo0, H, W, C1H_SEG);
+    if constexpr (Row::kRing) {   // the zero tap's slot and the tails of all ten row buffers meet zero weights: finite
+      for (int e = st; e < C1M_RING * C1H_SEG; e += 256) reinterpret_cast<unsigned *>(in_s)[e] = 0u;
+    }
+    __syncthreads();              // (every wave of the workgroup: nobody's first row store may be overtaken by the zeroing)
+    auto weights_dma = [&](int kh, int wbuf) __attribute__((always_inline)) {
+      const char *wsrc = reinterpret_cast<const char *>(wt1h) + (size_t)kh * C1H_WBYTES;
+#pragma unroll
+      for (int i = 0; i < (C1H_WBYTES / 1024 + 3) / 4; ++i) {   // 21 pieces of 1 KiB over the 4 staging waves
+        const int j = wave - 4 + 4 * i;
+        if (j < C1H_WBYTES / 1024)
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 1024 + lane * 16), (lptr_t)(w_s + wbuf * C1H_WBYTES + j * 1024),
+                                           16, 0, 0);
+      }
+    };
+    auto store_row = [&](const typename Row::Data &dd, int input_row) __attribute__((always_inline)) {
+      typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+      _Float16 *base = reinterpret_cast<_Float16 *>(in_s) + slot_of(input_row);
+      if constexpr (Row::kRing) {
+        row.scatter(dd, [&](int e, float v) __attribute__((always_inline)) { base[e] = (_Float16)v; });
+      } else {
+        half4_t *dst = reinterpret_cast<half4_t *>(base);
+#pragma unroll
+        for (int i = 0; i < C1H_IN4; ++i) {
+          const int q = st + 256 * i;
+          const floatx4 v = row.scaled(dd, i);
+          if (q < C1H_SEG / 4) dst[q] = __builtin_convertvector(v, half4_t);
+        }
+      }
+    };
+    // What a step needs that the steps before it have not staged: the top n rows of its window.  The first step of a chain
+    // in the band's FIRST quad: the whole window (4 rows); kh = 1 of a later quad: two rows (its chain has three steps for
+    // four output rows); every other step: one row.  ks is a compile-time constant wherever it matters (14 unrolled steps
+    // per loop iteration): the per-step code has no data-dependent branches left but "first quad of the band?".
+    auto row_base = [&](int quad) __attribute__((always_inline)) -> int { return 2 * (rb0 + C1M_QUAD * quad) - 3; };
+    // The staging is pipelined TWO steps deep: during step s the rows of step s + 1 -- fetched during step s - 1 -- are
+    // scaled and stored, and the global loads of step s + 2's rows are issued (into the other of two register sets), so a
+    // row has a whole step (~1.3 us) to arrive.  One step deep, every step waited for the memory latency of its own rows.
+    typename Row::Data setA[2], setB[2];
+    // fetch (into a register set) the top rows of the window of step (quad, KS); returns how many (<= 2)
+    auto issue = [&](auto KS, int quad, typename Row::Data *set) __attribute__((always_inline)) -> int {
+      constexpr int ks = decltype(KS)::value;
+      constexpr int kh = ks < 4 ? 2 * ks : 2 * ks - 7;
+      const int top = row_base(quad) + kh + 6;
+      row.load(set[0], top);
+      if (ks == 4 || (ks == 0 && quad == 0)) {
+        row.load(set[1], top - 2);
+        return 2;
+      }
+      return 1;
+    };
+    // scale, round and store the rows of step (quad, KS) out of their register set, then start the LDS-DMA of its weight row
+    auto commit = [&](auto KS, int quad, const typename Row::Data *set) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value;
+      constexpr int kh = ks < 4 ? 2 * ks : 2 * ks - 7;
+      const int top = row_base(quad) + kh + 6;
+      store_row(set[0], top);
+      if (ks == 4 || (ks == 0 && quad == 0)) store_row(set[1], top - 2);
+      if ((ks == 0 || ks == 4) && quad == 0) {   // the band's first window of a chain: its two older rows, on the spot
+        typename Row::Data extra[2];
+        row.load(extra[0], top - 4);
+        row.load(extra[1], top - 6);
+        store_row(extra[0], top - 4);
+        store_row(extra[1], top - 6);
+      }
+      weights_dma(kh, (7 * quad + ks) & 1);
+    };
+    // End of a step for a staging wave: its LDS stores and everything OLDER than the `newer` row loads it has just issued
+    // (this step's weight DMA in particular) must have landed; the row loads themselves stay in flight across the barrier
+    // -- __syncthreads() would wait for them too (vmcnt(0)) and put their latency back into every step.  A row is
+    // kLoadsPerRow load instructions when the rows are on the aligned grid; otherwise the count is data dependent and the
+    // wave waits for everything.
+    constexpr int kLoadsPerRow = (SRC & 1) ? C1H_IN4 : 0;
+    auto step_barrier = [&](int newer_rows) __attribute__((always_inline)) {
+      if (kLoadsPerRow > 0 && newer_rows == 2) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * kLoadsPerRow) : "memory");
+      } else if (kLoadsPerRow > 0 && newer_rows == 1) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kLoadsPerRow) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    // (the fences keep the program order the vmcnt arithmetic of step_barrier counts on: weight DMA, THEN the new row loads)
+    auto order_fence = [&]() __attribute__((always_inline)) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#ifdef DVSG_STAMPS
+    unsigned long long st_work = 0, st_wait = 0, st_load = 0, st_t = C1_STAMP();
+#endif
+    typedef std::integral_constant<int, 0> K0;
+    typedef std::integral_constant<int, 1> K1;
+    issue(K0{}, 0, setA);
+    commit(K0{}, 0, setA);
+    order_fence();
+    int inflight = nsteps > 1 ? issue(K1{}, 0, setB) : 0;
+    order_fence();
+    step_barrier(inflight);
+#ifdef DVSG_STAMPS
+    st_t = C1_STAMP();
+#endif
+    // One step of the staging waves, K = 0..13 within a pair of quads: during step s = (quad, ks) store step s + 1's rows
+    // (in the set of the other parity, fetched a step ago) and fetch step s + 2's into this parity's set.
+    auto stager_step = [&](auto KK, int quad_pair) __attribute__((always_inline)) -> bool {
+      constexpr int K = decltype(KK)::value;
+      constexpr int ks = K % 7, ks1 = (K + 1) % 7, ks2 = (K + 2) % 7;
+      const int quad = quad_pair + K / 7, quad1 = quad_pair + (K + 1) / 7, quad2 = quad_pair + (K + 2) / 7;
+      const int sidx = 7 * quad + ks;
+      if (sidx >= nsteps) return false;
+      typename Row::Data *cur = (K & 1) ? setA : setB;    // step s + 1's rows
+      typename Row::Data *nxt = (K & 1) ? setB : setA;    // step s + 2's rows go here
+#ifdef DVSG_STAMPS
+      { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long n_ = C1_STAMP(); st_load += n_ - st_t; st_t = n_; }
+#endif
+      if (sidx + 1 < nsteps) commit(std::integral_constant<int, ks1>{}, quad1, cur);
+      order_fence();
+      const int fl = sidx + 2 < nsteps ? issue(std::integral_constant<int, ks2>{}, quad2, nxt) : 0;
+      order_fence();
+#ifdef DVSG_STAMPS
+      { const unsigned long long n_ = C1_STAMP(); st_work += n_ - st_t; st_t = n_; }
+#endif
+      step_barrier(fl);
+#ifdef DVSG_STAMPS
+      { const unsigned long long n_ = C1_STAMP(); st_wait += n_ - st_t; st_t = n_; }
+#endif
+      return true;
+    };
+    for (int qp = 0; qp < nq; qp += 2) {
+#define C1M_STEP(K) if (!stager_step(std::integral_constant<int, K>{}, qp)) break;
+      C1M_STEP(0) C1M_STEP(1) C1M_STEP(2) C1M_STEP(3) C1M_STEP(4) C1M_STEP(5) C1M_STEP(6)
+      C1M_STEP(7) C1M_STEP(8) C1M_STEP(9) C1M_STEP(10) C1M_STEP(11) C1M_STEP(12) C1M_STEP(13)
+#undef C1M_STEP
+    }
+#ifdef DVSG_STAMPS
+    if (tid == 256 && blockIdx.x < 65536) {
+      g_c1_stamps[(size_t)blockIdx.x * 8 + 4] = st_work;   // staging wave: loads issued + rows stored + DMA issued, all steps
+      g_c1_stamps[(size_t)blockIdx.x * 8 + 5] = st_wait;   // staging wave: waiting at the step barriers
+      g_c1_stamps[(size_t)blockIdx.x * 8 + 7] = st_load;   // staging wave: waiting for the rows fetched a step earlier
+    }
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------------------- multiplying waves
+  floatx16 acc[C1M_QUAD][2];   // [output row of the quad][channel block]; rows = channels (A = weights), columns = pixels
+#pragma unroll
+  for (int j = 0; j < C1M_QUAD; ++j)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][ni][q] = 0.f;
+  // bias of the 32 channels a lane ends up with: 32 ni + 8 g + 4 h + {0..3}
+  float4 bias4[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[ni][g] = *reinterpret_cast<const float4 *>(bias + 32 * ni + 8 * g + 4 * h);
+  __syncthreads();                                   // pairs with the staging waves' barrier after the LDS zeroing
+  // A quad's results: bias, ReLU, float16 -- and a TRANSPOSE through LDS, because a lane holds 16 channels of ONE pixel
+  // and storing them as they are (8 bytes per lane, 32 different cache lines per instruction) took 13 500 cycles per quad,
+  // a quarter of the kernel.  Space: two row buffers of the even-row ring that are dead between the quad's last step
+  // (kh = 5: window a + 5 .. a + 11) and the staging for the next quad's kh = 1 (window a + 9 .. a + 15), i.e. the
+  // slots of rows a + 5 and a + 7; each wave transposes its own 32 pixels x 64 channels there (144-byte pixel stride),
+  // row by row, and writes 16 bytes per lane: 8 full 128-byte lines per store instruction.  No barrier: LDS operations
+  // of one wave complete in order.
+  auto flush_quad = [&](int quad) __attribute__((always_inline)) {
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    constexpr int PXS = 72;   // halves per pixel in the transpose buffer
+    _Float16 *tb = reinterpret_cast<_Float16 *>(in_s) + slot_of(2 * (rb0 + C1M_QUAD * quad) - 3 + (wave < 2 ? 5 : 7)) +
+                   (wave & 1) * (32 * PXS);
+    const int cpx = lane >> 3, chunk = lane & 7;      // read side: 8 pixels per pass, 8 chunks of 16 bytes per pixel
+#pragma unroll
+    for (int j = 0; j < C1M_QUAD; ++j) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bb = bias4[ni][g];
+          floatx4 v = {acc[j][ni][4 * g] + bb.x, acc[j][ni][4 * g + 1] + bb.y, acc[j][ni][4 * g + 2] + bb.z,
+                       acc[j][ni][4 * g + 3] + bb.w};
+          v = __builtin_elementwise_max(v, floatx4{0.f, 0.f, 0.f, 0.f});
+          *reinterpret_cast<half4_t *>(tb + r * PXS + 32 * ni + 8 * g + 4 * h) = __builtin_convertvector(v, half4_t);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[j][ni][4 * g + q] = 0.f;
+        }
+      const int ho = rb0 + C1M_QUAD * quad + j;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int p = 8 * pass + cpx;
+        const halfx8 v = *reinterpret_cast<const halfx8 *>(tb + p * PXS + 8 * chunk);
+        const int pxo = wo0 + 32 * wave + p;
+        if (ho < Ho && pxo < Wo) *reinterpret_cast<halfx8 *>(y + (((size_t)b * Ho + ho) * Wo + pxo) * 64 + 8 * chunk) = v;
+      }
+    }
+  };
+  __syncthreads();                                   // the first window and weight row are in place
+#ifdef DVSG_STAMPS
+  unsigned long long m_work = 0, m_wait = 0, m_flush = 0, m_t = C1_STAMP();
+  const unsigned long long m_begin = m_t;
+#endif
+  for (int s = 0; s < nsteps; ++s) {
+    const int quad = s / 7, ks = s - 7 * quad;
+    if (ks == 0 && quad > 0) flush_quad(quad - 1);
+#ifdef DVSG_STAMPS
+    { const unsigned long long n_ = C1_STAMP(); m_flush += n_ - m_t; m_t = n_; }
+#endif
+    const int w0 = window_of(s);
+    // LDS byte offsets of this lane's fragments, each in ONE register (laundered through an empty asm), so that the ten
+    // t-steps differ by the read instruction's own offset field (<= 1020 bytes); left alone the compiler keeps "lane part +
+    // (LDS base + t offset)" and spends a v_add_u32 per read -- 80 VALU slots per step on the port the MFMAs issue through
+    typedef const __attribute__((address_space(3))) unsigned *lds_u32_t;
+    typedef const __attribute__((address_space(3))) halfx8 *lds_h8_t;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    unsigned pix_off[C1M_QUAD];
+#pragma unroll
+    for (int j = 0; j < C1M_QUAD; ++j) {
+      pix_off[j] = lds0 + 2 * C1H_WBYTES + 2 * slot_of(w0 + 2 * j) + 4 * (kConv1Cin * (wave * 32 + r) + 4 * h);
+      asm volatile("" : "+v"(pix_off[j]));
+    }
+    unsigned w_off = lds0 + (s & 1) * C1H_WBYTES + 2 * (r * C1H_LD + 8 * h);
+    asm volatile("" : "+v"(w_off));
+    struct Frag {
+      union {
+        unsigned u[4];
+        halfx8 v;
+      } p[C1M_QUAD];
+      halfx8 w[2];
+    };
+    auto read_frag = [&](Frag &f, int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) f.w[ni] = *(lds_h8_t)(size_t)(w_off + 2 * ni * 32 * C1H_LD + 32 * t);
+#pragma unroll
+      for (int j = 0; j < C1M_QUAD; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.p[j].u[q] = *(lds_u32_t)(size_t)(pix_off[j] + 4 * (8 * t + q));
+    };
+    Frag fr[2];
+    read_frag(fr[0], 0);
+#pragma unroll
+    for (int t = 0; t < C1H_STEPS; ++t) {
+      if (t + 1 < C1H_STEPS) read_frag(fr[(t + 1) & 1], t + 1);
+      const Frag &f = fr[t & 1];
+#pragma unroll
+      for (int j = 0; j < C1M_QUAD; ++j)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[j][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[ni], f.p[j].v, acc[j][ni], 0, 0, 0);
+      // This wave is the only one that multiplies on its SIMD, so the next fragments' 10 LDS reads must issue BETWEEN this
+      // step's MFMAs -- each of which keeps the matrix pipe busy for 32 cycles -- not in front of them: grouped
+      // [reads][8 MFMAs] a t-step took 350 cycles instead of 256.
+#define C1M_GROUP(NREADS)                                                      \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */            \
+  __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0); /* LDS reads */
+      C1M_GROUP(2) C1M_GROUP(2) C1M_GROUP(1) C1M_GROUP(1) C1M_GROUP(1) C1M_GROUP(1) C1M_GROUP(1) C1M_GROUP(1)
+#undef C1M_GROUP
+    }
+#ifdef DVSG_STAMPS
+    { const unsigned long long n_ = C1_STAMP(); m_work += n_ - m_t; m_t = n_; }
+#endif
+    __syncthreads();
+#ifdef DVSG_STAMPS
+    { const unsigned long long n_ = C1_STAMP(); m_wait += n_ - m_t; m_t = n_; }
+#endif
+  }
+  flush_quad(nq - 1);
+#ifdef DVSG_STAMPS
+  if (tid == 0 && blockIdx.x < 65536) {
+    unsigned long long *o = g_c1_stamps + (size_t)blockIdx.x * 8;
+    o[0] = m_work;    // multiplying wave: fragment reads + MFMAs, all steps
+    o[1] = m_wait;    // multiplying wave: waiting at the step barriers
+    o[2] = m_flush;   // multiplying wave: bias / ReLU / stores between quads
+    o[3] = (unsigned long long)nsteps;
+    o[6] = C1_STAMP() - m_begin;
+  }
+#endif
+}
+
+// ----------------------------------------------------------------------------------------
 // conv1 for the "f32s" precision: conv1_kernel's decomposition and staging (one output row x 128 pixels x
 // 64 channels per workgroup, the input row segment prefetched into registers under the previous kernel
 // row's MFMAs, scale_RGB applied while staging, overlapping windows read in place), with the products
@@ -1055,7 +1409,25 @@ __global__ __launch_bounds__(256) void maxpool_p_kernel(const void *__restrict__
   store4_p(y, e * 4, m);
 }
 
-int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = 4 waves (measured equal or better), 1 = 8
+// Bands of the marching kernel: the launch must give each of the 256 CUs (one workgroup each) several bands' worth of
+// work, and a band should be long enough to amortise its first window (4 + 4 rows staged with nothing to multiply): at
+// least 3 workgroups per CU with >= 4 quads (16 output rows) per band, else 0 = do not use the kernel.  Returns the number
+// of bands per column tile and image; *quads_per_band the quads of each.
+int march_bands(int B, int Ho, int wtiles, int *quads_per_band) {
+  const int quads = (Ho + C1M_QUAD - 1) / C1M_QUAD;
+  const long cols = (long)B * wtiles;
+  for (int qpb = 8; qpb >= 4; --qpb) {               // 32 .. 16 output rows per band
+    const int bands = (quads + qpb - 1) / qpb;
+    if (cols * bands >= 3 * 256) {
+      if (quads_per_band) *quads_per_band = qpb;
+      return bands;
+    }
+  }
+  return 0;
+}
+
+int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = auto; 1 = float32 kernel with 8 waves; 2 = float16 output from
+                          // the float32 multiply; 3 = float16, one output row per workgroup; 4 = never the marching kernel; 5 = always
 
 }  // namespace
 
@@ -1096,6 +1468,27 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
     DVSG_C1(DVSG_K_SPLIT, 256, static_cast<const _Float16 *>(wt1s), static_cast<float *>(y));
   } else if (out_prec == kF16 && wt1h && g_conv1_variant == 3) {   // A/B: one output row per workgroup
     DVSG_C1(DVSG_K_F16, 256, static_cast<const _Float16 *>(wt1h), static_cast<_Float16 *>(y));
+  } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2 && g_conv1_variant != 4 &&
+             (g_conv1_variant == 5 || march_bands(B, Ho, wtiles, nullptr) > 0)) {
+    // big launches: marching, wave-specialised workgroups (conv1_f16_march_kernel), one per CU
+    // (conv1_variant 5 forces it at any size, bands of <= 3 quads: the parity tests run it on small frames)
+    int qpb = 0;
+    int bands = march_bands(B, Ho, wtiles, &qpb);
+    if (g_conv1_variant == 5) {
+      qpb = 3;
+      bands = ((Ho + C1M_QUAD - 1) / C1M_QUAD + qpb - 1) / qpb;
+    }
+    const dim3 mgrid((unsigned)((long)wtiles * bands * B));
+    const _Float16 *wp = static_cast<const _Float16 *>(wt1h);
+    _Float16 *yp = static_cast<_Float16 *>(y);
+    switch (SRC) {
+      case 0: hipLaunchKernelGGL((conv1_f16_march_kernel<0>), mgrid, dim3(512), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, bands, qpb); break;
+      case 1: hipLaunchKernelGGL((conv1_f16_march_kernel<1>), mgrid, dim3(512), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, bands, qpb); break;
+      case 2: hipLaunchKernelGGL((conv1_f16_march_kernel<2>), mgrid, dim3(512), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, bands, qpb); break;
+      case 3: hipLaunchKernelGGL((conv1_f16_march_kernel<3>), mgrid, dim3(512), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, bands, qpb); break;
+      case 4: hipLaunchKernelGGL((conv1_f16_march_kernel<4>), mgrid, dim3(512), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, bands, qpb); break;
+      default: hipLaunchKernelGGL((conv1_f16_march_kernel<5>), mgrid, dim3(512), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, bands, qpb); break;
+    }
   } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2) {   // two output rows per workgroup (conv1_f16_pair_kernel)
     const int hpairs = (Ho + 1) / 2;
     const long pblocks = (long)wtiles * hpairs * B;

@@ -235,3 +235,41 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
             assert float((outs[1] - outs[1 << 30]).abs().mean()) < 2e-5 * scale, case
     finally:
         _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)
+
+
+@pytest.mark.parametrize("source", ["window", "ring_f32", "ring_u8"])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100), (3, 33, 47), (1, 8, 8), (1, 1, 1), (2, 30, 600), (1, 100, 301)])
+def test_conv1_f16_kernels_agree(net, source, B, H, W):
+    """The three float16 conv1 kernels -- one output row per workgroup (conv1_variant 3), two rows with the kernel rows
+    visited as two chains (4 = the default of small launches), and the marching, wave-specialised kernel of the big
+    launches (5 forces it here: bands of three quads, so a frame is cut into several bands and the last quad / band is
+    ragged) -- multiply the same float16 operands and accumulate in float32; the kernel-row order differs between the
+    first and the other two (0..6 against 0, 2, 4, 6, 1, 3, 5), so those agree to float32 re-association -- one float16
+    ulp of the output -- and the last two, which add the same products in the same order, bit for bit."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    rng = np.random.default_rng(H * 1000 + W)
+    if source == "window":
+        x = torch.from_numpy(inputs.window_frames(77, B, H, W)).cuda()
+        run = lambda: net.tap(x, 0, precision="f16")
+    else:
+        n = 9
+        pool = (rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8) if source == "ring_u8"
+                else rng.uniform(0, 1, (n, H, W, 3)).astype(np.float32))
+        pool = torch.from_numpy(pool).cuda()
+        table = torch.from_numpy(rng.integers(0, n, (B, 7)).astype(np.int32)).cuda()
+        run = lambda: net.forward_ring(pool, table, precision="f16", stage=0)
+    outs = {}
+    try:
+        for v in (3, 4, 5):
+            _lib.call("dvsg_debug_set_option", b"conv1_variant", v)
+            outs[v] = run().clone()
+    finally:
+        _lib.call("dvsg_debug_set_option", b"conv1_variant", 0)
+    assert torch.equal(outs[4], outs[5]), "pair vs marching kernel: max diff %g" % float((outs[4] - outs[5]).abs().max())
+    ref = outs[3]
+    # one float16 ulp of the value, plus the float32 re-association noise of a 1029-term sum that cancels to ~0 in front
+    # of the ReLU (absolute: relative to the tensor's scale, not to the value)
+    tol = 2.0 ** -10 * ref.abs() + 1e-5 * float(ref.abs().max())
+    bad = (outs[4] - ref).abs() > tol
+    assert not bool(bad.any()), "%d values off, worst %g" % (int(bad.sum()), float(((outs[4] - ref).abs() - tol).max()))
