@@ -280,6 +280,10 @@ def main():
                     help="f32 (default, the reference's arithmetic: the headline number); f32s: float32 storage / "
                          "accumulation with products from two float16 pieces per operand (dtype f32x2f16); f16: float16 "
                          "activations, hi / lo float16 weight pairs")
+    ap.add_argument("--source", default="window", choices=["window", "ring_f32", "ring_u8"],
+                    help="window (default): the [B,H,W,21] float32 window tensor the reference feeds (eval.py:106-110), "
+                         "dvsg_stabilize_*; ring_f32 / ring_u8: a pool of 7 B RGB frames (float32, or raw uint8 with the / 255. "
+                         "fused) + the [B,7] index table, windows assembled inside conv1's load stage: dvsg_stabilize_ring_*")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the batch of one step is split over (LocNet.stabilize); 2 is <1 %% faster "
                          "but concurrent launches make the per-kernel hipEvent durations of `roofline` meaningless")
@@ -354,6 +358,14 @@ def main():
         net = LocNet(weights)
         patches = gpu_windows(B, H, W, 1234 + rank, dev)
         u_t = patches[..., 18:].contiguous()
+        ring_pool = ring_table = None
+        if args.source != "window":
+            # the same windows as a frame ring: frame 7 b + s of the pool is slot s of window b
+            ring_pool = patches.reshape(B, H, W, 7, 3).permute(0, 3, 1, 2, 4).reshape(7 * B, H, W, 3).contiguous()
+            if args.source == "ring_u8":
+                ring_pool = (ring_pool * 255.0).round_().to(torch.uint8)
+            ring_table = torch.arange(7 * B, dtype=torch.int32, device=dev).reshape(B, 7).contiguous()
+            patches = u_t = None
     outs = [torch.empty((B, H, W, 3), device=dev) for _ in range(2)]
     F_t = torch.empty((B, 25, 2), device=dev)
     gather_bufs = None
@@ -377,8 +389,11 @@ def main():
         else:
             for b0 in range(0, B, CB):   # dvsg_stabilize_*, CB windows per call
                 b1 = min(B, b0 + CB)
-                net.stabilize(patches[b0:b1], u_t[b0:b1], out[b0:b1], F_t[b0:b1], n_streams=args.streams,
-                              precision=args.precision)
+                if ring_pool is not None:
+                    net.stabilize_ring(ring_pool, ring_table[b0:b1], out[b0:b1], F_t[b0:b1], precision=args.precision)
+                else:
+                    net.stabilize(patches[b0:b1], u_t[b0:b1], out[b0:b1], F_t[b0:b1], n_streams=args.streams,
+                                  precision=args.precision)
         if dist is not None and not args.no_gather:
             if on_host:   # rehearsal path: synchronous, through host memory
                 dist.gather(out.cpu(), gather_bufs[slot] if rank == 0 else None, dst=0)
@@ -483,10 +498,11 @@ def main():
                                         if dist is not None and backend == "nccl" else None),
                        "ms_per_step_over_ranks": rank_ms,
                        "gather": bool(dist is not None and not args.no_gather), "streams_per_gpu": args.streams,
+                       "source": "n/a" if flow_mode else args.source,
                        "weights": "n/a" if flow_mode else "synthetic seed 0 (reference ships no checkpoint)"},
             "roofline": roofline,
         }
-        if world == 1 and not flow_mode and args.precision == "f32" and not args.no_secondary:
+        if world == 1 and not flow_mode and args.precision == "f32" and not args.no_secondary and args.source == "window":
             # Beside the line of record (exact float32 matrix cores), the same workload in the "f32s" precision:
             # float32 accumulation, products from two float16 pieces per operand (22 significant bits).  It passes the
             # float32 path's own parity bounds (tests/test_gpu_f32s.py) but is not the reference's arithmetic, so it is
