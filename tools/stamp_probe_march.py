@@ -23,7 +23,7 @@ buf = np.zeros((65536, 8), dtype=np.uint64)
 assert lib.dvsg_debug_read_conv1_stamps(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.nbytes)) == 0
 st = buf[buf[:, 3] > 0].astype(np.float64)
 steps = st[:, 3]
-print("conv1_f16_march_kernel B=%d %dx%d: %d workgroups sampled, %.0f steps each (s_memtime ticks = 100 MHz: x ~19-24 for shader cycles)"
+print("conv1_f16_march_kernel B=%d %dx%d: %d workgroups sampled, %.0f steps each (s_memtime ticks: shader-clock cycles on this part)"
       % (B, W, H, len(st), np.median(steps)))
 for i, nm in ((0, "multiplying wave: fragment reads + 80 MFMAs"), (1, "multiplying wave: at the step barrier"),
               (2, "multiplying wave: flush (per step, amortised)"), (4, "staging wave: loads + scale + stores + DMA issue"),
