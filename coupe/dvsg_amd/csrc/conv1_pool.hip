@@ -925,9 +925,11 @@ void conv1_f16_march_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1
 
   if (stager) {
     // ------------------------------------------------------------------------------ staging waves
-    // (their few instructions go first when both waves of a SIMD are ready: with the default oldest-first arbitration the
-    // staging wave -- the younger one -- only issued while the multiplying wave was stalled: stamps, tools/stamp_probe_march.py)
-    __builtin_amdgcn_s_setprio(3);
+    // Their few instructions go first when both waves of a SIMD are ready (s_setprio): with the default oldest-first
+    // arbitration the staging wave -- the younger one -- only issues while the multiplying wave is stalled, and a step takes
+    // 5550 cycles instead of 4950 (stamps, tools/stamp_probe_march.py).  The multiplying waves raise their own priority for
+    // the flush, where they have no MFMAs to hide behind.
+    __builtin_amdgcn_s_setprio(2);
     const int st = tid - 256;
     typedef typename Conv1RowSel<256, C1H_IN4, SRC>::type Row;
     Row row;
@@ -1095,38 +1097,66 @@ void conv1_f16_march_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1
   // and storing them as they are (8 bytes per lane, 32 different cache lines per instruction) took 13 500 cycles per quad,
   // a quarter of the kernel.  Space: two row buffers of the even-row ring that are dead between the quad's last step
   // (kh = 5: window a + 5 .. a + 11) and the staging for the next quad's kh = 1 (window a + 9 .. a + 15), i.e. the
-  // slots of rows a + 5 and a + 7; each wave transposes its own 32 pixels x 64 channels there (144-byte pixel stride),
-  // row by row, and writes 16 bytes per lane: 8 full 128-byte lines per store instruction.  No barrier: LDS operations
-  // of one wave complete in order.
+  // slots of rows a + 5 and a + 7; each wave transposes its own 32 pixels there, half a row's channels at a time, and
+  // writes 16 bytes per lane (64 contiguous bytes per pixel).  No barrier: LDS operations of one wave complete in order.
   auto flush_quad = [&](int quad) __attribute__((always_inline)) {
     typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    constexpr int PXS = 72;   // halves per pixel in the transpose buffer
+    // unit = (output row j, channel block ni): 32 pixels x 32 channels = 2 KB, 80-byte pixel stride (16-byte aligned reads,
+    // 20 r mod 64 banks: conflict-free 8-byte writes); two buffers per wave, so that unit u + 1 is written while unit u's
+    // reads are in flight -- the LDS round trips of the 8 units of a quad overlap instead of adding up
+    constexpr int PXS = 40;                           // halves per pixel
+    constexpr int UNIT = 32 * PXS;                    // halves per buffer
     _Float16 *tb = reinterpret_cast<_Float16 *>(in_s) + slot_of(2 * (rb0 + C1M_QUAD * quad) - 3 + (wave < 2 ? 5 : 7)) +
-                   (wave & 1) * (32 * PXS);
-    const int cpx = lane >> 3, chunk = lane & 7;      // read side: 8 pixels per pass, 8 chunks of 16 bytes per pixel
+                   (wave & 1) * (2 * UNIT);
+    const int cpx = lane >> 2, chunk = lane & 3;      // read side: 16 pixels per pass, 4 chunks of 16 bytes per pixel
+    auto write_unit = [&](int u) __attribute__((always_inline)) {
+      const int j = u >> 1, ni = u & 1;
+      _Float16 *dst = tb + (u & 1) * UNIT + r * PXS + 4 * h;
 #pragma unroll
-    for (int j = 0; j < C1M_QUAD; ++j) {
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = bias4[ni][g];
+        floatx4 v = {acc[j][ni][4 * g], acc[j][ni][4 * g + 1], acc[j][ni][4 * g + 2], acc[j][ni][4 * g + 3]};
+        v = v + floatx4{bb.x, bb.y, bb.z, bb.w};
+        v = __builtin_elementwise_max(v, floatx4{0.f, 0.f, 0.f, 0.f});
+        *reinterpret_cast<half4_t *>(dst + 8 * g) = __builtin_convertvector(v, half4_t);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+        for (int q = 0; q < 4; ++q) acc[j][ni][4 * g + q] = 0.f;
+      }
+    };
+    halfx8 rd[2][2];
+    auto read_unit = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 bb = bias4[ni][g];
-          floatx4 v = {acc[j][ni][4 * g] + bb.x, acc[j][ni][4 * g + 1] + bb.y, acc[j][ni][4 * g + 2] + bb.z,
-                       acc[j][ni][4 * g + 3] + bb.w};
-          v = __builtin_elementwise_max(v, floatx4{0.f, 0.f, 0.f, 0.f});
-          *reinterpret_cast<half4_t *>(tb + r * PXS + 32 * ni + 8 * g + 4 * h) = __builtin_convertvector(v, half4_t);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[j][ni][4 * g + q] = 0.f;
-        }
+      for (int pass = 0; pass < 2; ++pass)
+        rd[u & 1][pass] = *reinterpret_cast<const halfx8 *>(tb + (u & 1) * UNIT + (16 * pass + cpx) * PXS + 8 * chunk);
+    };
+    auto store_unit = [&](int u) __attribute__((always_inline)) {
+      const int j = u >> 1, ni = u & 1;
       const int ho = rb0 + C1M_QUAD * quad + j;
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int p = 8 * pass + cpx;
-        const halfx8 v = *reinterpret_cast<const halfx8 *>(tb + p * PXS + 8 * chunk);
-        const int pxo = wo0 + 32 * wave + p;
-        if (ho < Ho && pxo < Wo) *reinterpret_cast<halfx8 *>(y + (((size_t)b * Ho + ho) * Wo + pxo) * 64 + 8 * chunk) = v;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int pxo = wo0 + 32 * wave + 16 * pass + cpx;
+#ifdef DVSG_FLUSH_NOSTORE   // (diagnostic: what do the global stores of the flush cost?)
+        if (ho < -1 && pxo < Wo)
+#else
+        if (ho < Ho && pxo < Wo)
+#endif
+          *reinterpret_cast<halfx8 *>(y + (((size_t)b * Ho + ho) * Wo + pxo) * 64 + 32 * ni + 8 * chunk) = rd[u & 1][pass];
       }
+    };
+    // software pipeline: a unit's reads are issued a whole unit of arithmetic before the stores that need them (the LDS is
+    // ~70 % busy with the other SIMDs' fragment reads: a round trip is several hundred cycles).  LDS operations of one wave
+    // complete in order, so read_unit(u) sees write_unit(u) and write_unit(u + 2) cannot overtake read_unit(u).
+    __builtin_amdgcn_s_setprio(3);
+    write_unit(0);
+    write_unit(1);
+    read_unit(0);
+#pragma unroll
+    for (int u = 0; u < 2 * C1M_QUAD; ++u) {
+      if (u + 1 < 2 * C1M_QUAD) read_unit(u + 1);
+      if (u + 2 < 2 * C1M_QUAD) write_unit(u + 2);
+      store_unit(u);
     }
+    __builtin_amdgcn_s_setprio(0);
   };
   __syncthreads();                                   // the first window and weight row are in place
 #ifdef DVSG_STAMPS
