@@ -152,3 +152,61 @@ def test_ring_rejects_bad_arguments(net):
     with pytest.raises(DvsgError, match="NULL"):
         _lib.call("dvsg_stabilize_ring_f32", net.handle, 0, pool.data_ptr(), 4, 0, 1, 16, 16, out.data_ptr(),
                   F.data_ptr(), 0, 0, ws.data_ptr(), nbytes, 0)
+
+
+@pytest.mark.parametrize("precision,variant", [("f32", 0), ("f16", 0), ("f16", 5)])
+def test_a_ring_step_replays_from_a_captured_hip_graph(net, precision, variant):
+    """`dvsg_stabilize_ring_*` allocates and synchronises nothing: it is captured into a HIP graph as it stands -- the
+    marching float16 conv1 kernel (conv1_variant 5 forces it at this size) with its role-split waves and hand-counted
+    barriers included -- and replays bit for bit."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    B, H, W, n = 2, 96, 160, 14
+    frames = inputs.smooth_frames(281, n, H, W)
+    pool = torch.from_numpy((frames * 255).astype(np.uint8)).cuda()
+    table = torch.from_numpy(np.random.default_rng(3).integers(0, n, (B, 7)).astype(np.int32)).cuda()
+    out = torch.empty((B, H, W, 3), device="cuda")
+    F = torch.empty((B, 25, 2), device="cuda")
+    _lib.call("dvsg_debug_set_option", b"conv1_variant", variant)
+    try:
+        net.stabilize_ring(pool, table, out, F, precision=precision)
+        torch.cuda.synchronize()
+        ref_out, ref_F = out.clone(), F.clone()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            net.stabilize_ring(pool, table, out, F, precision=precision)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            net.stabilize_ring(pool, table, out, F, precision=precision)
+        for _ in range(3):
+            out.zero_()
+            F.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(F, ref_F) and torch.equal(out, ref_out)
+    finally:
+        _lib.call("dvsg_debug_set_option", b"conv1_variant", 0)
+
+
+def test_init_vars_feeds_the_gpu_model(tmp_path, synthetic_weights):
+    """model.py:125-154 end to end: the trunk from a (synthetic) slim checkpoint, conv1 and the dense head from the
+    caller's arrays, and the model that results is the oracle's on the merged weights."""
+    import torch
+    from coupe.dvsg_amd import tf_checkpoint as tfc
+    from coupe.dvsg_amd.model import Session, StabNet
+    from coupe.dvsg_amd.weights import PREFIX, make_synthetic_weights
+    from oracle import networks as onet
+    donor = make_synthetic_weights(seed=5)
+    ckpt = {k[:-2][len(PREFIX):]: v for k, v in donor.items() if k.startswith(PREFIX + "resnet_v1_50/")}
+    ckpt["resnet_v1_50/conv1/weights"] = np.zeros((7, 7, 3, 64), np.float32)
+    path = str(tmp_path / "resnet_v1_50.ckpt")
+    tfc.write_bundle(path, ckpt)
+    H, W = 40, 64
+    model = StabNet(H, W).init_vars(synthetic_weights, ckpt_path=path)
+    ins, outs = model.get_evaluation_model(7)
+    x = inputs.window_frames(291, 1, H, W)
+    F = Session().run(outs["F_t"], {ins["patches_t"]: x, ins["u_t"]: x[..., 18:]})
+    merged = tfc.init_from_slim_checkpoint(synthetic_weights, path)
+    assert np.abs(F - onet.localizationNet(x, 25, merged)).max() <= 1e-5
+    assert np.abs(F - onet.localizationNet(x, 25, synthetic_weights)).max() > 1e-4      # it really is another network
