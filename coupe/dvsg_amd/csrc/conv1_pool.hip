@@ -571,6 +571,7 @@ void conv1_f16_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h, con
   row.init(src, tid, b, wo0, H, W, C1H_SEG);
   if constexpr (Row::kRing) {   // both images: the zero tap's slot and the tail are read against zero weights
     for (int e = tid; e < C1H_SEG; e += 256) reinterpret_cast<unsigned *>(in_s)[e] = 0u;
+    __syncthreads();   // the first scatter writes halves of words other threads zero: the zeros must land first
   }
 
   typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -713,6 +714,7 @@ void conv1_f16_pair_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1h
   row.init(src, tid, b, wo0, H, W, C1H_SEG);
   if constexpr (Row::kRing) {   // both images: the zero tap's slot and the tail are read against zero weights
     for (int e = tid; e < C1H_SEG; e += 256) reinterpret_cast<unsigned *>(in_s)[e] = 0u;
+    __syncthreads();   // the first scatter writes halves of words other threads zero: the zeros must land first
   }
   typename Row::Data d0, d1;
 

@@ -87,6 +87,38 @@ def test_uint8_ring_is_the_float_ring_of_the_converted_frames(net, precision, B,
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("variant", [4, 3, 0])
+def test_float16_conv1_from_a_ring_at_full_frames(net, dtype, variant):
+    """Full 1280x720 frames, a batch small enough for the two-rows-per-workgroup kernel (variant 4; 3 = the one-row
+    kernel, 0 = what the launcher picks), several pools: every value equals the gathered window's.  Regression: the
+    kernels that scatter a ring row into LDS zero the row images first, and without a barrier between the two a zeroed
+    word could land AFTER a neighbour thread's float16 half of it -- a few pixels per launch at this size, never at the
+    small shapes above (found by tools/soak_march.py, round 3)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    B, H, W = 4, 720, 1280
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    try:
+        for rep in range(6):
+            if dtype == "u8":
+                pool = torch.randint(0, 256, (7 * B, H, W, 3), generator=gen, device="cuda", dtype=torch.uint8)
+                fr = torch.empty((7 * B, H, W, 3), device="cuda")
+                _lib.call("dvsg_frames_u8_to_f32", pool.data_ptr(), pool.numel() // 3, 0, fr.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+            else:
+                pool = fr = torch.rand((7 * B, H, W, 3), generator=gen, device="cuda")
+            table = torch.randint(0, 7 * B, (B, 7), generator=gen, device="cuda", dtype=torch.int32)
+            x = _gather(fr, table)
+            _lib.call("dvsg_debug_set_option", b"conv1_variant", variant)
+            got = net.forward_ring(pool, table, precision="f16", stage=0)
+            want = net.tap(x, 0, precision="f16")
+            bad = int((got != want).sum())
+            assert bad == 0, "pool %d: %d values differ, max %g" % (rep, bad, float((got - want).abs().max()))
+    finally:
+        _lib.call("dvsg_debug_set_option", b"conv1_variant", 0)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16"])
 def test_stabilize_ring_is_gather_plus_stabilize(net, precision):
     """The whole evaluation graph from the ring: F_t, the source grid and the warped frames of
