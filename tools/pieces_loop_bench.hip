@@ -25,6 +25,11 @@
 // 4.5-6 % end to end (nobody multiplies during a tile's prologue / epilogue with one workgroup per CU).
 // H8-H10: 256 x 128 tiles with 64-byte (32-k) stages, 48 KB of LDS, TWO workgroups per CU: 620-665 -- the geometry of
 // conv_gemm_wide16.hip (+2.7 % end to end at 720p batch 16, +5.7 % at 4K batch 32).
+// H11-H15 (round 3): 256 x 256 tiles, 8 waves of 64 x 128 or 128 x 64, ONE workgroup per CU, 3-4 stages of 32 KB or 2 of
+// 64 KB -- a third fewer L2 -> LDS bytes per product than 256 x 128: 680-695 (64-byte stages), 686-732 (128-byte stages):
+// +4 % over H8.  At 660+ (1.3 PFLOP/s executed) the loop is no longer bound by the L2 -> LDS stream but by the matrix
+// pipe at the clock the chip holds under this load; the product's distance to it (441 for the 3x3 class, 535 for the
+// 1x1 class) is prologue / epilogue / HBM time, not tile geometry.  Not built.
 //   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
 #include <hip/hip_runtime.h>
 
@@ -207,6 +212,11 @@ int main() {
   run<256, 128, 4, 2, 2, false, true, 64>("H8 f16 256x128, 8 x (64x64), 64-byte stages, 2 stages, 2 WG/CU", 2, src, src_bytes, out);
   run<256, 128, 4, 2, 2, true, true, 64>("H9 H8 pipelined", 2, src, src_bytes, out);
   run<256, 128, 4, 2, 3, false, true, 64>("H10 H8 with 3 stages (72 KiB), 2 WG/CU", 2, src, src_bytes, out);
+  run<256, 256, 4, 2, 3, false, true, 64>("H11 f16 256x256, 8 x (64x128), 64-byte stages, 3 stages (96 KiB), 1 WG/CU", 1, src, src_bytes, out);
+  run<256, 256, 4, 2, 3, true, true, 64>("H12 H11 pipelined", 1, src, src_bytes, out);
+  run<256, 256, 4, 2, 4, false, true, 64>("H13 H11 with 4 stages (128 KiB)", 1, src, src_bytes, out);
+  run<256, 256, 2, 4, 3, false, true, 64>("H14 f16 256x256, 8 x (128x64), 3 stages, 1 WG/CU", 1, src, src_bytes, out);
+  run<256, 256, 4, 2, 2, false, true, 128>("H15 f16 256x256, 8 x (64x128), 128-byte stages, 2 stages (128 KiB), 1 WG/CU", 1, src, src_bytes, out);
   }
   return 0;
 }
