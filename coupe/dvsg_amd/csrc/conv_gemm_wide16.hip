@@ -22,6 +22,9 @@
 // launches and keeps conv_gemm_kernel for the rest.
 #include "cnn_device.h"
 #include "cnn_kernels.h"
+#ifdef DVSG_STAMPS
+#include <cstdio>
+#endif
 
 namespace dvsg {
 namespace {
@@ -41,7 +44,15 @@ struct ConvWide16Dev {
   int stride, pad;
   int res_H, res_W, res_stride;
   int M, K, mtiles, ntiles;
+#ifdef DVSG_STAMPS
+  int stamp;   // this launch writes its per-workgroup phase times to g_w16_stamps
+#endif
 };
+
+#ifdef DVSG_STAMPS  // diagnostic build (tools/stamp_probe_wide16.py): per-workgroup phase times, wave 0 of each workgroup
+__device__ unsigned long long g_w16_stamps[8 * 65536];
+#define W16_STAMP() __builtin_amdgcn_s_memtime()
+#endif
 
 // SPLIT = false: the 128 weight rows of a tile are 128 output channels of a PLAIN float16 weight matrix [Cout][K] (layers
 // whose weights do not need the lo piece -- locnet.hip's pair policy): the "lo" accumulators are simply the tile's second
@@ -66,6 +77,10 @@ void conv_wide16_kernel(ConvWide16Dev p) {
   typedef __attribute__((address_space(3))) void *lptr_t;
 
   // nt fastest: the n-tiles of a pixel tile run back to back on one XCD and re-read its activations out of L2
+#ifdef DVSG_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = W16_STAMP();
+#endif
   const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   const int m0 = mt * WBM;
@@ -157,11 +172,24 @@ void conv_wide16_kernel(ConvWide16Dev p) {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+#ifdef DVSG_STAMPS
+  const unsigned long long t_first = W16_STAMP();
+  st[0] = t_first - t_begin;   // index setup + the first stage's round trip
+#endif
   __builtin_amdgcn_sched_barrier(0);
   compute_stage(0);
   __builtin_amdgcn_sched_barrier(0);
   for (int kt = 1; kt < KT - 1; ++kt) {
+#ifdef DVSG_STAMPS
+    const unsigned long long b0 = W16_STAMP();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long b1 = W16_STAMP();
+    __syncthreads();
+    st[1] += b1 - b0;             // this wave's part of the next stage has not landed
+    st[2] += W16_STAMP() - b1;    // at the barrier
+#else
     __syncthreads();   // vmcnt(0): stage kt has landed; everyone has read stage kt - 1
+#endif
     issue_stage((kt + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
     compute_stage(kt & 1);
@@ -169,6 +197,11 @@ void conv_wide16_kernel(ConvWide16Dev p) {
   }
   __syncthreads();
   compute_stage((KT - 1) & 1);
+#ifdef DVSG_STAMPS
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t_loop = W16_STAMP();
+  st[3] = t_loop - t_first;   // the K loop, waits included
+#endif
 
   // ---- epilogue: 64 output channels at a time, rounds of 128 pixels through a [128][64] float32 transpose
   // (SPLIT: one channel half, hi + 2^-11 lo; plain: two channel halves, the accumulators as they are)
@@ -200,9 +233,16 @@ void conv_wide16_kernel(ConvWide16Dev p) {
         rv[i] = load4(p.res + roff);
       }
     }
+#ifdef DVSG_STAMPS
+    const unsigned long long e0 = W16_STAMP();
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the stage buffers (first round) / the previous round's rows have been read
     asm volatile("" ::: "memory");
+#ifdef DVSG_STAMPS
+    const unsigned long long e1 = W16_STAMP();
+    st[4] += e1 - e0;   // barrier before the transpose (the other waves' MFMAs / reads)
+#endif
     if ((wm >> 1) == rho) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -214,6 +254,13 @@ void conv_wide16_kernel(ConvWide16Dev p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef DVSG_STAMPS
+    const unsigned long long e2 = W16_STAMP();
+    st[5] += e2 - e1;   // transpose stores + barrier
+    if (RES != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long e3 = W16_STAMP();
+    st[6] += e3 - e2;   // residual rows not there yet (and, second round, the first round's stores still in flight)
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = row0 + 32 * i;
@@ -232,6 +279,16 @@ void conv_wide16_kernel(ConvWide16Dev p) {
     }
   }
   }
+#ifdef DVSG_STAMPS
+  const unsigned long long t_issued = W16_STAMP();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_end = W16_STAMP();
+  if (p.stamp && tid == 0 && blockIdx.x < 65536) {
+    unsigned long long *o = g_w16_stamps + (size_t)blockIdx.x * 8;
+    o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3]; o[4] = st[4]; o[5] = st[5]; o[6] = st[6];
+    o[7] = ((t_end - t_begin) << 24) | ((t_end - t_issued) & 0xffffffull);   // lifetime | drain of the last stores
+  }
+#endif
 }
 
 template <int KS, bool SPLIT>
@@ -253,6 +310,19 @@ int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
 
 }  // namespace
 
+#ifdef DVSG_STAMPS
+int g_w16_stamp_sel = 0;   // KS * 100000000 + Cin * 10000 + Cout of the launches that record
+extern "C" int dvsg_debug_wide16_stamp_select(int sel) {   // and forget the stamps recorded so far
+  g_w16_stamp_sel = sel;
+  void *sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_w16_stamps)) != hipSuccess) return -3;
+  return hipMemset(sym, 0, sizeof(unsigned long long) * 8 * 65536) == hipSuccess && hipDeviceSynchronize() == hipSuccess ? 0 : -3;
+}
+extern "C" int dvsg_debug_read_wide16_stamps(void *host, size_t bytes) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w16_stamps), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
+
 // p: a float16 layer -- stacked [hi | lo] weights (p.wsplit, Cout % 64 == 0) or plain ones (Cout % 128 == 0) -- with
 // Cin % 64 == 0; the caller has opened the ProfScope
 int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
@@ -267,6 +337,10 @@ int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
   d.K = p.ksize * p.ksize * p.Cin;
   d.mtiles = (int)((M + WBM - 1) / WBM);
   d.ntiles = p.wsplit ? p.Cout / 64 : p.Cout / 128;
+#ifdef DVSG_STAMPS
+  d.stamp = g_w16_stamp_sel == p.ksize * 100000000 + p.Cin * 10000 + p.Cout;
+  if (d.stamp) std::fprintf(stderr, "wide16 stamps: ks %d Cin %d Cout %d M %ld tiles %d x %d res %d relu %d\n", p.ksize, p.Cin, p.Cout, M, d.mtiles, d.ntiles, p.res != nullptr, p.relu);
+#endif
   const int res = !p.res ? 0 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
   if (p.wsplit) return p.ksize == 3 ? launch_ks<3, true>(d, p.relu != 0, res, s) : launch_ks<1, true>(d, p.relu != 0, res, s);
   DVSG_REQUIRE(p.Cout % 128 == 0, "conv_wide16: plain weights need Cout %% 128 == 0, got %d", p.Cout);

@@ -29,7 +29,11 @@
 // 64 KB -- a third fewer L2 -> LDS bytes per product than 256 x 128: 680-695 (64-byte stages), 686-732 (128-byte stages):
 // +4 % over H8.  At 660+ (1.3 PFLOP/s executed) the loop is no longer bound by the L2 -> LDS stream but by the matrix
 // pipe at the clock the chip holds under this load; the product's distance to it (441 for the 3x3 class, 535 for the
-// 1x1 class) is prologue / epilogue / HBM time, not tile geometry.  Not built.
+// 1x1 class) is not tile geometry.  Not built.
+// H16 / H17: H8 fed like the product -- every row 64 bytes of a pixel's channel run, i.e. HALF a 128-byte line, the other
+// half wanted in the next stage (1x1 layers) or nine stages later (3x3 layers): 477-575 / 334-346 instead of 632-660.
+// H18-H22: whole-line rows (128-byte stages): 192 x 128 at two workgroups per CU 453-469 on pitched rows, 256 x 128 at one
+// workgroup per CU 547-569.
 //   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
 #include <hip/hip_runtime.h>
 
@@ -41,11 +45,11 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128, int HALF = 0>
 __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stages, const char *src, size_t src_bytes) {
   constexpr int NW = WM * WN, MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int PER = (BM + BN) * ROWB / 1024 / NW;   // LDS-DMA instructions (1 KiB each) per wave and stage
+  constexpr int PER = ((BM + BN) * ROWB / 1024 + NW - 1) / NW;   // LDS-DMA instructions (1 KiB each) per wave and stage
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
@@ -65,7 +69,21 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int g = wave + NW * i;
-      __builtin_amdgcn_global_load_lds((gptr_t)(my + (size_t)s * STAGE + g * 1024 + lane * 16), (lptr_t)(dst + g * 1024), 16, 0, 0);
+      if (g >= STAGE / 1024) break;   // (wave-uniform; only geometries whose stage is not a multiple of NW KiB)
+      if constexpr (HALF == 0) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(my + (size_t)s * STAGE + g * 1024 + lane * 16), (lptr_t)(dst + g * 1024), 16, 0, 0);
+      } else if constexpr (HALF < 0) {
+        // whole 128-byte lines, one per row, rows at a 512-byte pitch (a pixel's channel run in a 256-channel tensor)
+        __builtin_amdgcn_global_load_lds((gptr_t)(my + (size_t)(s / 4) * 4 * STAGE + (s % 4) * 128 + (size_t)(g * 8 + (lane >> 3)) * 512 + (lane & 7) * 16),
+                                         (lptr_t)(dst + g * 1024), 16, 0, 0);
+      } else {
+        // the product's activation rows: 64 bytes of a pixel's channel run per stage, i.e. HALF a 128-byte line per row;
+        // the line's other half is read HALF stages later (1: the next 32-channel chunk of a 1x1 layer; 9: of a 3x3 layer)
+        const int grp = s / (2 * HALF), pos = s % (2 * HALF), slot = pos % HALF, half = pos / HALF;
+        const char *base = my + ((size_t)grp * HALF + slot) * 2 * STAGE;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + g * 2048 + (lane >> 2) * 128 + half * 64 + (lane & 3) * 16),
+                                         (lptr_t)(dst + g * 1024), 16, 0, 0);
+      }
     }
   };
   // F16 (the float16 mode: f16 activations, [hi | lo] weight rows stacked along N): four 16-k steps per 128-byte
@@ -161,11 +179,11 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
   if (sum == 12345.678f) out[tid] = sum;  // keep the accumulators live
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128, int HALF = 0>
 void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, float *out) {
   const int stages = 72, grid = 256 * wgs_per_cu * 6;
   const size_t lds = (size_t)NS * (BM + BN) * ROWB;
-  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16, ROWB>;
+  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16, ROWB, HALF>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -212,6 +230,13 @@ int main() {
   run<256, 128, 4, 2, 2, false, true, 64>("H8 f16 256x128, 8 x (64x64), 64-byte stages, 2 stages, 2 WG/CU", 2, src, src_bytes, out);
   run<256, 128, 4, 2, 2, true, true, 64>("H9 H8 pipelined", 2, src, src_bytes, out);
   run<256, 128, 4, 2, 3, false, true, 64>("H10 H8 with 3 stages (72 KiB), 2 WG/CU", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, true, 64, 1>("H16 H8, rows = half lines, other half in the next stage (1x1 layers)", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, true, 64, 9>("H17 H8, rows = half lines, other half 9 stages later (3x3 layers)", 2, src, src_bytes, out);
+  run<192, 128, 3, 2, 2, false, true, 128>("H18 f16 192x128, 6 x (64x64), 128-byte stages, 2 stages (80 KiB), 2 WG/CU", 2, src, src_bytes, out);
+  run<192, 128, 3, 2, 2, false, true, 128, -1>("H19 H18, rows = whole lines at a 512-byte pitch", 2, src, src_bytes, out);
+  run<128, 128, 2, 4, 2, false, true, 128, -1>("H20 H0 (128x128, 128-byte stages), rows = whole lines at a 512-byte pitch", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 3, false, true, 128, -1>("H21 f16 256x128, 8 x (64x64), 128-byte stages, 3 stages (144 KiB), 1 WG/CU, whole lines", 1, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, true, 128, -1>("H22 H21 with 2 stages (96 KiB)", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 3, false, true, 64>("H11 f16 256x256, 8 x (64x128), 64-byte stages, 3 stages (96 KiB), 1 WG/CU", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 3, true, true, 64>("H12 H11 pipelined", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 4, false, true, 64>("H13 H11 with 4 stages (128 KiB)", 1, src, src_bytes, out);
