@@ -50,6 +50,23 @@ def test_tf_warp_half_pixel_is_average():
     assert np.allclose(out[0, :, 7, 0], 0.5 * im[0, :, 7, 0], atol=1e-7)   # fades into the zero ring
 
 
+def test_tf_warp_is_scipys_bilinear_with_a_zero_ring():
+    """Independent of the restatement: warp_with_optical_flow.py:96-176 samples the frame bilinearly at (x + u, y + v)
+    with zeros outside -- SciPy's map_coordinates(order=1, mode="grid-constant", cval=0): it blends into the zero ring too."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(5)
+    H, W = 17, 23
+    im = rng.uniform(0, 1, (1, H, W, 2)).astype(np.float32)
+    flow = rng.uniform(-3.0, 3.0, (1, H, W, 2)).astype(np.float32)
+    got = oflow.tf_warp(im, flow, H, W)[0]
+    gy, gx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    xq = (gx.astype(np.float32) + flow[0, ..., 0]).astype(np.float64)
+    yq = (gy.astype(np.float32) + flow[0, ..., 1]).astype(np.float64)
+    for c in range(2):
+        ref = map_coordinates(im[0, :, :, c].astype(np.float64), [yq, xq], order=1, mode="grid-constant", cval=0.0)
+        assert np.abs(got[..., c] - ref).max() < 2e-6
+
+
 def test_tps_zero_vector_gives_identity_map():                 # (4)
     B, H, W = 1, 24, 40
     coord = inputs.v_src(B)
@@ -85,6 +102,44 @@ def test_tps_interpolates_control_points():                    # (6)
             d2 = ((coord[b, k].astype(np.float64) - coord[b].astype(np.float64)) ** 2).sum(1)
             basis = np.concatenate([[1.0], coord[b, k], d2 * np.log(d2 + 1e-6)])
             assert np.abs(T[b] @ basis - (coord[b, k] + vec[b, k])).max() < 1e-5
+
+
+def test_tps_map_is_scipys_thin_plate_spline():
+    """Independent of the restatement: the map of ThinPlateSpline.py:92-166 is THE thin-plate spline through the control
+    points (kernel d^2 log(d^2 + 1e-6) = 2 r^2 log r up to the epsilon, affine part, side conditions in W's last three
+    rows), so SciPy's RBFInterpolator (kernel r^2 log r, degree 1, no smoothing) through the same points must give the
+    same source coordinates everywhere on the grid -- a scaled kernel changes the weights, not the interpolant."""
+    from scipy.interpolate import RBFInterpolator
+    H, W, B = 24, 40, 2
+    coord = inputs.v_src(B).astype(np.float64)
+    vec = inputs.control_vectors(3, B, scale=0.2).astype(np.float64)
+    _, xs, ys = otps.ThinPlateSpline(np.zeros((B, H, W, 1), np.float32), coord, vec, (H, W))
+    xs, ys = xs.reshape(B, -1), ys.reshape(B, -1)
+    gx, gy = np.meshgrid(np.linspace(-1, 1, W), np.linspace(-1, 1, H))
+    pts = np.stack([gx.ravel(), gy.ravel()], 1)
+    for b in range(B):
+        ref = RBFInterpolator(coord[b], coord[b] + vec[b], kernel="thin_plate_spline", degree=1)(pts)
+        assert np.abs(xs[b] - ref[:, 0]).max() < 2e-5 and np.abs(ys[b] - ref[:, 1]).max() < 2e-5
+
+
+def test_sampler_a_is_plain_bilinear_inside_the_frame():
+    """Independent of the restatement: away from the border ThinPlateSpline.py:30-90 is ordinary bilinear interpolation
+    at pixel coordinates ((x + 1) W / 2, (y + 1) H / 2) -- SciPy's map_coordinates(order=1) on the same points."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(11)
+    H, W = 19, 31
+    im = rng.uniform(0, 1, (1, H, W, 2)).astype(np.float32)
+    n = 400
+    xp = rng.uniform(0.0, W - 1.001, n)
+    yp = rng.uniform(0.0, H - 1.001, n)
+    x = (xp * 2.0 / W - 1.0).astype(np.float32)
+    y = (yp * 2.0 / H - 1.0).astype(np.float32)
+    got = otps.interpolate_a(np.tile(im, (1, 1, 1, 1)), x[None, :H * W], y[None, :H * W])[0]
+    xq = (x.astype(np.float64) + 1.0) * W / 2.0          # the coordinates the float32 inputs really name
+    yq = (y.astype(np.float64) + 1.0) * H / 2.0
+    for c in range(2):
+        ref = map_coordinates(im[0, :, :, c].astype(np.float64), [yq, xq], order=1, mode="nearest")
+        assert np.abs(got[:, c] - ref).max() < 2e-5
 
 
 def test_tps2_is_tps_with_target():
