@@ -48,11 +48,6 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
 // float16 mode, big launches: 256 x 128 tiles with 64-byte K stages (conv_gemm_wide16.hip); called by launch_conv_gemm
 int launch_conv_wide16(const ConvGemm &p, hipStream_t s);
 void set_wide16_min_tiles(int v);
-// float16 mode, expand layers (1x1, stride 1, Cin 128 / 256, Cout >= 2 Cin) of big launches: the pixel tile resident in LDS,
-// the output-channel groups walked by the workgroup (conv_expand16.hip); called by launch_conv_gemm
-bool conv_expand16_takes(const ConvGemm &p);
-int launch_conv_expand16(const ConvGemm &p, hipStream_t s);
-void set_expand16(int v);           // diagnostic (dvsg_debug_set_option "expand16")   // diagnostic (dvsg_debug_set_option "wide16_min_tiles")
 // Zeroes n split-K / stream-K tickets with a KERNEL: a hipMemsetAsync captured into a HIP graph (memset node) did not
 // take effect on the second and later replays of the graph on ROCm 7.2 (tests/test_gpu_cnn.py::test_a_step_replays_...).
 int launch_zero_tickets(int *tickets, size_t n, hipStream_t s);

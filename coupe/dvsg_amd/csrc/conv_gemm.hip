@@ -710,8 +710,6 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   // its whole panel past the 4 MB L2 (1.2 GB per launch).  With mt fastest an XCD stays on one or
   // two panels and re-reads the (much smaller) activations instead.
   d.mt_fast = d.ntiles > 1 && (size_t)(wide ? 128 : 64) * d.K * elem_size(p.prec) >= ((size_t)2 << 20);
-  // float16 mode: the expand layers of big launches keep their pixel tile resident in LDS (conv_expand16.hip)
-  if (split && g_conv_variant != 5 && conv_expand16_takes(p)) return launch_conv_expand16(p, s);
   // float16 mode: a launch of several rounds of tiles runs in the 256 x 128 / 64-byte-stage geometry (conv_gemm_wide16.hip)
   if (split && g_conv_variant != 5 && (long)((M + 255) / 256) * (p.Cout / 64) >= g_wide16_min_tiles) return launch_conv_wide16(p, s);
   // ... and so does a plain-float16 layer (no lo piece: locnet.hip's pair policy) whose 128-channel tiles fill the chip

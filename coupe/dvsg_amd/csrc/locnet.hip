@@ -742,10 +742,6 @@ int dvsg_debug_set_option(const char *name, int value) {
     set_wide16_min_tiles(value);
     return DVSG_OK;
   }
-  if (std::strcmp(name, "expand16") == 0) {
-    set_expand16(value);
-    return DVSG_OK;
-  }
   if (std::strcmp(name, "conv1_variant") == 0) {
     set_conv1_variant(value);
     return DVSG_OK;

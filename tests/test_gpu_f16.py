@@ -237,62 +237,6 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
         _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)
 
 
-def test_resident_tile_expand_kernel_matches_float32_math_and_the_wide_tiles():
-    """conv_expand16.hip (1x1, stride 1, Cin 128 / 256, Cout >= 2 Cin: the pixel tile resident in LDS, the workgroup
-    walks the output-channel groups) forced onto small ragged layers -- M not a multiple of the 128- / 192-pixel tile,
-    fewer pixels than one tile, residual of the output's shape / subsampled / none, with and without ReLU -- against
-    float32 math on the unrounded weights and against conv_wide16_kernel on the same layer: the same float16 products,
-    summed in the same K order (32 k per stage, hi and lo apart), so the two agree to the last float32 bit."""
-    import torch
-    from coupe.dvsg_amd import _lib
-    dev = torch.device("cuda:0")
-    g = torch.Generator(device=dev).manual_seed(9)
-    st = torch.cuda.current_stream().cuda_stream
-    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
-    cases = [  # cin, cout, B, h, w, residual mode (0 none, 1 same shape, 2 subsampled), relu
-        (128, 512, 3, 21, 29, 1, 1), (256, 1024, 2, 23, 31, 1, 1), (128, 256, 5, 9, 13, 0, 0), (256, 512, 1, 37, 41, 0, 0),
-        (128, 512, 2, 16, 17, 2, 1), (256, 1024, 1, 7, 9, 2, 1), (256, 1024, 1, 20, 20, 1, 0), (128, 512, 1, 3, 5, 1, 1)]
-    try:
-        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 1)
-        for cin, cout, B, h, w, rmode, relu in cases:
-            x = (torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3).half()
-            w32 = (torch.rand((cout, cin), generator=g, device=dev) - 0.5) * (2.0 / cin ** 0.5)
-            hi = w32.half()
-            lo = ((w32 - hi.float()) * 2048.0).half()
-            ws = torch.stack([hi.reshape(cout // 64, 64, cin), lo.reshape(cout // 64, 64, cin)], 1).reshape(2 * cout, cin).contiguous()
-            bias = torch.rand((cout,), generator=g, device=dev) - 0.5
-            res_stride = 1
-            if rmode == 1:
-                res = (torch.rand((B, h, w, cout), generator=g, device=dev) - 0.5).half()
-                res_at = res
-            elif rmode == 2:
-                res_stride = 2
-                res = (torch.rand((B, 2 * (h - 1) + 1, 2 * (w - 1) + 1, cout), generator=g, device=dev) - 0.5).half()
-                res_at = res[:, ::2, ::2, :]
-            else:
-                res, res_at = None, None
-            outs = {}
-            for mode in (2, 0):   # resident-tile kernel forced / 256 x 128 tiles
-                _lib.call("dvsg_debug_set_option", b"expand16", mode)
-                y = torch.full((B, h, w, cout), float("nan"), device=dev, dtype=torch.float16)
-                _lib.call("dvsg_conv_gemm_f16s", x.data_ptr(), ws.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else 0,
-                          y.data_ptr(), B, h, w, cin, cout, 1, 1, relu, res_stride, scratch.data_ptr(), scratch.numel(), st)
-                outs[mode] = y.float()
-            ref = torch.nn.functional.linear(x.float(), w32, bias)
-            if res_at is not None:
-                ref = ref + res_at.float()
-            if relu:
-                ref = torch.relu(ref)
-            scale = max(1.0, float(ref.abs().max()))
-            case = (cin, cout, B, h, w, rmode, relu)
-            assert bool(torch.isfinite(outs[2]).all()), case
-            assert float((outs[2] - ref).abs().max()) < 1.2e-3 * scale, case
-            assert torch.equal(outs[2], outs[0]), (case, float((outs[2] - outs[0]).abs().max()))
-    finally:
-        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)
-        _lib.call("dvsg_debug_set_option", b"expand16", 1)
-
-
 @pytest.mark.parametrize("source", ["window", "ring_f32", "ring_u8"])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100), (3, 33, 47), (1, 8, 8), (1, 1, 1), (2, 30, 600), (1, 100, 301)])
 def test_conv1_f16_kernels_agree(net, source, B, H, W):
