@@ -34,6 +34,8 @@
 // half wanted in the next stage (1x1 layers) or nine stages later (3x3 layers): 477-575 / 334-346 instead of 632-660.
 // H18-H22: whole-line rows (128-byte stages): 192 x 128 at two workgroups per CU 453-469 on pitched rows, 256 x 128 at one
 // workgroup per CU 547-569.
+// H23-H26: the 256 x 128 tile as 4 FAT waves of 128 x 64 (0.75 KB of LDS fragment reads per MFMA instead of 1, two waves per
+// SIMD): 480 / 349 where H8's eight waves run 660 / 635 -- two waves per SIMD do not cover each other's round trips.
 //   hipcc -O3 --offload-arch=gfx950 tools/pieces_loop_bench.hip -o build/pieces_loop_bench && build/pieces_loop_bench
 #include <hip/hip_runtime.h>
 
@@ -237,6 +239,10 @@ int main() {
   run<128, 128, 2, 4, 2, false, true, 128, -1>("H20 H0 (128x128, 128-byte stages), rows = whole lines at a 512-byte pitch", 2, src, src_bytes, out);
   run<256, 128, 4, 2, 3, false, true, 128, -1>("H21 f16 256x128, 8 x (64x64), 128-byte stages, 3 stages (144 KiB), 1 WG/CU, whole lines", 1, src, src_bytes, out);
   run<256, 128, 4, 2, 2, false, true, 128, -1>("H22 H21 with 2 stages (96 KiB)", 1, src, src_bytes, out);
+  run<256, 128, 2, 2, 2, false, true, 64>("H23 f16 256x128, 4 FAT waves of 128x64 (0.75 KB of LDS reads per MFMA), 64-byte stages, 2 WG/CU", 2, src, src_bytes, out);
+  run<256, 128, 2, 2, 2, true, true, 64>("H24 H23 pipelined", 2, src, src_bytes, out);
+  run<256, 128, 2, 2, 2, false, true, 64, 1>("H25 H23, half-line rows, other half next stage (1x1)", 2, src, src_bytes, out);
+  run<256, 128, 2, 2, 2, false, true, 64, 9>("H26 H23, half-line rows, other half 9 stages later (3x3)", 2, src, src_bytes, out);
   run<256, 256, 4, 2, 3, false, true, 64>("H11 f16 256x256, 8 x (64x128), 64-byte stages, 3 stages (96 KiB), 1 WG/CU", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 3, true, true, 64>("H12 H11 pipelined", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 4, false, true, 64>("H13 H11 with 4 stages (128 KiB)", 1, src, src_bytes, out);
