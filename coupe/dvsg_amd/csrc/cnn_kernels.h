@@ -35,6 +35,7 @@ struct ConvGemm {
   int ksize, stride, pad;
   int res_H, res_W, res_stride;
   int relu;
+  const void *wt_packed = nullptr;   // kF16, optional: the rows of `wt` packed stage by stage for conv_gemm_wide16.hip (launch_pack_wide16)
   int wsplit = 0;     // kF16: wt is the stacked layout [Cout/64][128][K] (64 hi rows, then 64 lo rows); kF32: wt is
                       // [Cout][K/32][32 hi halves | 32 lo halves] and products are formed from float16 pieces (conv_gemm.hip)
   // optional split-K scratch (small batches): partial-tile slabs and kSplitKMaxTiles zeroed int tickets
@@ -48,6 +49,10 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
 // float16 mode, big launches: 256 x 128 tiles with 64-byte K stages (conv_gemm_wide16.hip); called by launch_conv_gemm
 int launch_conv_wide16(const ConvGemm &p, hipStream_t s);
 void set_wide16_min_tiles(int v);
+// weights packed for that kernel: every 32-k stage of a 128-row tile contiguous, in the LDS image's chunk order
+size_t wide16_packed_bytes(int rows, int Cin, int ksize);
+int launch_pack_wide16(const void *wt, void *out, int rows, int Cin, int ksize, hipStream_t s);
+void set_wide16_packed(int v);      // diagnostic (dvsg_debug_set_option "wide16_packed")
 // Zeroes n split-K / stream-K tickets with a KERNEL: a hipMemsetAsync captured into a HIP graph (memset node) did not
 // take effect on the second and later replays of the graph on ROCm 7.2 (tests/test_gpu_cnn.py::test_a_step_replays_...).
 int launch_zero_tickets(int *tickets, size_t n, hipStream_t s);

@@ -38,6 +38,7 @@ __device__ const floatx4 g_zero16w = {0.f, 0.f, 0.f, 0.f};
 
 struct ConvWide16Dev {
   const _Float16 *x, *wt, *res;
+  const _Float16 *wtp;   // the weights again, packed stage by stage (pack_wide16_kernel), or nullptr
   const float *bias;
   _Float16 *y;
   int H, W, Cin, Ho, Wo, Cout;
@@ -121,6 +122,11 @@ void conv_wide16_kernel(ConvWide16Dev p) {
     wsrc = p.wt + ((size_t)nt * WBN + row) * p.K + 8 * (lpos ^ ((row >> 2) & 3));
   }
   // K order as in conv_gemm.hip: channel chunk outer, the KS x KS taps inner
+  // The weight rows of a stage: 64 bytes out of each of 128 rows that lie K elements apart -- 128 half lines, the other
+  // half of each wanted one stage (1x1) or nine stages (3x3) later.  The packed copy holds every stage of a tile as 8 KB
+  // in a row, already in the LDS image's chunk order: the same bytes as 64 whole lines, lane l of wave w fetching
+  // 16 bytes at 1024 w + 16 l (isolated loop, tools/pieces_loop_bench.hip H27 / H28: +15 % / +30 % with such stages).
+  const _Float16 *wpk = p.wtp ? p.wtp + (size_t)nt * p.K * WBN + wave * 512 + lane * 8 : nullptr;
   int s_kh = 0, s_kw = 0, s_c0 = 0;
   auto issue_stage = [&](int buf) __attribute__((always_inline)) {
     const _Float16 *xa = p.x + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
@@ -131,7 +137,12 @@ void conv_wide16_kernel(ConvWide16Dev p) {
       const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16w);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * WBM + 16 * (wave + NW * i)) * WROWB), 16, 0, 0);
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + wk), (lptr_t)(Bs + (buf * WBN + 16 * wave) * WROWB), 16, 0, 0);
+    const _Float16 *wfrom = wsrc + wk;
+    if (wpk) {   // (uniform)
+      wfrom = wpk;
+      wpk += WBN * WBKE;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)wfrom, (lptr_t)(Bs + (buf * WBN + 16 * wave) * WROWB), 16, 0, 0);
     if (KS > 1) {
       if (++s_kw == KS) {
         s_kw = 0;
@@ -308,6 +319,40 @@ int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
   return check_launch("conv_wide16_kernel");
 }
 
+// Packed weights for the kernel above: [tile of 128 rows][stage][row][chunk position][8 halves]; stage s of a tile is the
+// 32 k the kernel visits s-th (channel chunk outer, taps inner), position c' of row r holds chunk c' ^ ((r >> 2) & 3).
+__global__ void pack_wide16_kernel(const _Float16 *__restrict__ wt, _Float16 *__restrict__ out, int K, int Cin, int taps,
+                                   size_t nchunks) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int KT = K / WBKE;
+  const int pos = (int)(i & 3), row = (int)((i >> 2) & 127);
+  const size_t ts = i >> 9;   // tile * KT + stage
+  const int st = (int)(ts % KT);
+  const size_t tile = ts / KT;
+  const int chunk = pos ^ ((row >> 2) & 3);
+  const int k = (taps > 1 ? (st % taps) * Cin + (st / taps) * WBKE : st * WBKE) + 8 * chunk;
+  *reinterpret_cast<floatx4 *>(out + i * 8) = *reinterpret_cast<const floatx4 *>(wt + (tile * 128 + row) * K + k);
+}
+
+}  // namespace
+
+int g_wide16_packed = 1;   // dvsg_debug_set_option("wide16_packed", 0): weight stages fetched from the [rows][K] layout
+void set_wide16_packed(int v) { g_wide16_packed = v; }
+
+size_t wide16_packed_bytes(int rows, int Cin, int ksize) { return (size_t)rows * ksize * ksize * Cin * sizeof(_Float16); }
+
+// wt: `rows` weight rows of K = ksize^2 Cin float16 (stacked hi / lo rows, or plain ones), rows % 128 == 0, Cin % 64 == 0
+int launch_pack_wide16(const void *wt, void *out, int rows, int Cin, int ksize, hipStream_t s) {
+  DVSG_REQUIRE(wt && out && rows % 128 == 0 && Cin % 64 == 0 && (ksize == 1 || ksize == 3), "pack_wide16: bad arguments");
+  const int K = ksize * ksize * Cin;
+  const size_t nchunks = (size_t)rows * K / 8;
+  hipLaunchKernelGGL(pack_wide16_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, static_cast<const _Float16 *>(wt),
+                     static_cast<_Float16 *>(out), K, Cin, ksize * ksize, nchunks);
+  return check_launch("pack_wide16_kernel");
+}
+
+namespace {
 }  // namespace
 
 #ifdef DVSG_STAMPS
@@ -330,6 +375,7 @@ int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
   ConvWide16Dev d;
   d.x = static_cast<const _Float16 *>(p.x); d.wt = static_cast<const _Float16 *>(p.wt);
   d.res = static_cast<const _Float16 *>(p.res); d.bias = p.bias; d.y = static_cast<_Float16 *>(p.y);
+  d.wtp = g_wide16_packed ? static_cast<const _Float16 *>(p.wt_packed) : nullptr;
   d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
   d.stride = p.stride; d.pad = p.pad;
   d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;

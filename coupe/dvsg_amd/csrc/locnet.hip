@@ -33,6 +33,7 @@ struct ConvLayer {
   float *wt = nullptr;        // device, [cout][k*k*cin] float32 (conv1: [7][64][kConv1Ld])
   _Float16 *wt16 = nullptr;   // device, same layout in float16 (not for conv1)
   _Float16 *wt16s = nullptr;  // device, float16 hi / lo pairs [cout/64][128][k*k*cin] (conv_gemm.hip SPLIT; not for conv1)
+  _Float16 *wt16p = nullptr;  // device, wt16s packed stage by stage for conv_gemm_wide16.hip (cin % 64 == 0 layers)
   _Float16 *wt32s = nullptr;  // device, "f32s" pieces [cout][k*k*cin/32][32 hi | 32 lo] (conv_gemm.hip SPLIT, T = float; not for conv1)
   float *bias = nullptr;      // device, [cout] float32
   const void *weights(int prec, bool split) const {
@@ -162,6 +163,14 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
   if (int rc = upload(net, wt, &L->wt)) return rc;
   if (int rc = upload(net, wt16, &L->wt16)) return rc;
   if (int rc = upload(net, wt16s, &L->wt16s)) return rc;
+  if (L->cin % 64 == 0 && L->cout % 64 == 0) {   // the layers conv_gemm_wide16.hip can take
+    void *pk = nullptr;
+    DVSG_HIP(hipMalloc(&pk, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
+    net->allocs.push_back(pk);
+    if (int rc = launch_pack_wide16(L->wt16s, pk, 2 * L->cout, L->cin, L->ksize, nullptr)) return rc;
+    DVSG_HIP(hipStreamSynchronize(nullptr));
+    L->wt16p = static_cast<_Float16 *>(pk);
+  }
   if (int rc = upload(net, wt32s, &L->wt32s)) return rc;
   return upload(net, shift, &L->bias);
 }
@@ -301,6 +310,7 @@ int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int
   p.prec = prec == kF32S ? kF32 : prec;
   p.wsplit = prec == kF32S || (prec == kF16 && pairs);
   p.x = x; p.wt = L.weights(prec, p.wsplit != 0); p.bias = L.bias; p.res = res; p.y = y;
+  if (prec == kF16 && pairs) p.wt_packed = L.wt16p;
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
   p.res_H = res_H; p.res_W = res_W; p.res_stride = res_stride;
@@ -513,6 +523,23 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
   p.res_H = (p.Ho - 1) * res_stride + 1; p.res_W = (p.Wo - 1) * res_stride + 1;
   p.res_stride = res_stride;
   p.relu = relu;
+  if (prec == kF16 && wsplit && Cin % 64 == 0 && Cout % 64 == 0 && (ksize == 1 || ksize == 3)) {
+    // the packed copy conv_gemm_wide16.hip prefers, made here on every call (a test entry: the weights may have changed
+    // behind the same pointer) in a buffer that only grows
+    static void *packed = nullptr;
+    static size_t packed_bytes = 0;
+    const size_t need = wide16_packed_bytes(2 * Cout, Cin, ksize);
+    if (need > packed_bytes) {
+      DVSG_HIP(hipDeviceSynchronize());
+      if (packed) DVSG_HIP(hipFree(packed));
+      packed = nullptr;
+      packed_bytes = 0;
+      DVSG_HIP(hipMalloc(&packed, need));
+      packed_bytes = need;
+    }
+    if (int rc = launch_pack_wide16(wt, packed, 2 * Cout, Cin, ksize, as_stream(stream))) return rc;
+    p.wt_packed = packed;
+  }
   const size_t cbytes = align256((size_t)kSplitKMaxTiles * sizeof(int));
   if (scratch && scratch_bytes > cbytes) {  // [tickets | partial-tile slabs]
     if (int rc = launch_zero_tickets(static_cast<int *>(scratch), cbytes / sizeof(int), as_stream(stream))) return rc;
@@ -740,6 +767,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "wide16_min_tiles") == 0) {
     set_wide16_min_tiles(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "wide16_packed") == 0) {
+    set_wide16_packed(value);
     return DVSG_OK;
   }
   if (std::strcmp(name, "conv1_variant") == 0) {

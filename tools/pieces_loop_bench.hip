@@ -47,7 +47,7 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128, int HALF = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128, int HALF = 0, bool BCONT = false>
 __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stages, const char *src, size_t src_bytes) {
   constexpr int NW = WM * WN, MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int STAGE = (BM + BN) * ROWB;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
     for (int i = 0; i < PER; ++i) {
       const int g = wave + NW * i;
       if (g >= STAGE / 1024) break;   // (wave-uniform; only geometries whose stage is not a multiple of NW KiB)
-      if constexpr (HALF == 0) {
+      if (HALF == 0 || (BCONT && g >= BM * ROWB / 1024)) {   // (BCONT: the weight rows of a stage pre-packed contiguously)
         __builtin_amdgcn_global_load_lds((gptr_t)(my + (size_t)s * STAGE + g * 1024 + lane * 16), (lptr_t)(dst + g * 1024), 16, 0, 0);
       } else if constexpr (HALF < 0) {
         // whole 128-byte lines, one per row, rows at a 512-byte pitch (a pixel's channel run in a 256-channel tensor)
@@ -181,11 +181,11 @@ __global__ __launch_bounds__(64 * WM * WN) void loop_kernel(float *out, int stag
   if (sum == 12345.678f) out[tid] = sum;  // keep the accumulators live
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128, int HALF = 0>
+template <int BM, int BN, int WM, int WN, int NS, bool PIPE, bool F16 = false, int ROWB = 128, int HALF = 0, bool BCONT = false>
 void run(const char *name, int wgs_per_cu, const char *src, size_t src_bytes, float *out) {
   const int stages = 72, grid = 256 * wgs_per_cu * 6;
   const size_t lds = (size_t)NS * (BM + BN) * ROWB;
-  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16, ROWB, HALF>;
+  auto k = loop_kernel<BM, BN, WM, WN, NS, PIPE, F16, ROWB, HALF, BCONT>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -243,6 +243,8 @@ int main() {
   run<256, 128, 2, 2, 2, true, true, 64>("H24 H23 pipelined", 2, src, src_bytes, out);
   run<256, 128, 2, 2, 2, false, true, 64, 1>("H25 H23, half-line rows, other half next stage (1x1)", 2, src, src_bytes, out);
   run<256, 128, 2, 2, 2, false, true, 64, 9>("H26 H23, half-line rows, other half 9 stages later (3x3)", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, true, 64, 1, true>("H27 H16 (1x1 pattern) with the weight rows of a stage contiguous", 2, src, src_bytes, out);
+  run<256, 128, 4, 2, 2, false, true, 64, 9, true>("H28 H17 (3x3 pattern) with the weight rows of a stage contiguous", 2, src, src_bytes, out);
   run<256, 256, 4, 2, 3, false, true, 64>("H11 f16 256x256, 8 x (64x128), 64-byte stages, 3 stages (96 KiB), 1 WG/CU", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 3, true, true, 64>("H12 H11 pipelined", 1, src, src_bytes, out);
   run<256, 256, 4, 2, 4, false, true, 64>("H13 H11 with 4 stages (128 KiB)", 1, src, src_bytes, out);
