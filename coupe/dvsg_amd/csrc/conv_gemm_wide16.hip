@@ -39,6 +39,7 @@ __device__ const floatx4 g_zero16w = {0.f, 0.f, 0.f, 0.f};
 struct ConvWide16Dev {
   const _Float16 *x, *wt, *res;
   const _Float16 *wtp;   // the weights again, packed stage by stage (pack_wide16_kernel), or nullptr
+  int arows;             // 128-byte activation rows (conv_wide16a_kernel; wtp packed in order 1)
   const float *bias;
   _Float16 *y;
   int H, W, Cin, Ho, Wo, Cout;
@@ -302,10 +303,209 @@ void conv_wide16_kernel(ConvWide16Dev p) {
 #endif
 }
 
+// ----------------------------------------------------------------------------------------
+// The same tile with the ACTIVATION rows staged 128 bytes (64 k) at a time: a pixel's 64-byte piece is half a 128-byte
+// line, and the kernel above asks for a line's halves in different stages -- one stage apart in a 1x1 layer, nine in a
+// 3x3 layer (isolated loop, tools/pieces_loop_bench.hip: 660 with contiguous stages, 490-575 / 335 with such rows).  Here
+// an activation stage is a SUPER-stage of 64 k (whole lines: 256 rows x 128 bytes, two buffers = 64 KB) consumed as two
+// half-stages against two of the 8 KB weight stages (packed: launch_pack_wide16, order 1), still one barrier per 32 k
+// and 80 KB per workgroup, two per CU.  K order of a 3x3 layer: 64-channel chunk outer, taps inner, the chunk's two
+// halves innermost.  Packed weights only.
+// SPLIT = false: the 128 weight rows of a tile are 128 output channels of a PLAIN float16 weight matrix [Cout][K] (layers
+// whose weights do not need the lo piece -- locnet.hip's pair policy): the "lo" accumulators are simply the tile's second
+// 64 channels, same loop, half the bytes and MFMAs per output channel.
+template <int KS, bool RELU, int RES, bool SPLIT = true>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv_wide16a_kernel(ConvWide16Dev p) {
+  constexpr int NW = 8, MI = 2;
+  constexpr int AG = WBM / 8 / NW;    // 4 LDS-DMA instructions (8 rows of 128 bytes each) per wave and super-stage
+  constexpr int AROWB = 2 * WROWB;    // 128
+  constexpr float kLoScale = 1.0f / 2048.0f;
+  __shared__ __attribute__((aligned(16))) char lds[2 * WBM * AROWB + 2 * WBN * WROWB];   // 64 + 16 KiB
+  char *As = lds;
+  char *Bs = lds + 2 * WBM * AROWB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow = lane >> 3, lpos = lane & 7;   // activation DMA: 8 rows x 8 chunks per instruction
+  const int sw = (r >> 2) & 3;   // weight rows (64 bytes): chunk ^ (row >> 2) & 3
+  const int swa = (r >> 1) & 7;  // activation rows (128 bytes): chunk ^ (row >> 1) & 7
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  // nt fastest: the n-tiles of a pixel tile run back to back on one XCD and re-read its activations out of L2
+  const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int m0 = mt * WBM;
+
+  long a_off[AG];
+  unsigned a_mask[AG];
+  const bool dense = KS == 1 && p.stride == 1;   // a 1x1 / stride 1 layer is a row-major GEMM (conv_gemm.hip)
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    const int row = 8 * (wave + NW * i) + lrow;
+    const int chunk = lpos ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    const int mm = m < p.M ? m : 0;
+    if (dense) {
+      a_off[i] = (long)mm * p.Cin + 8 * chunk;
+      a_mask[i] = m < p.M ? 0x11u : 0u;
+      continue;
+    }
+    const int wo = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int ho = t % p.Ho;
+    const int b = t / p.Ho;
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + 8 * chunk;
+    unsigned mk = 0;
+    if (m < p.M) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        if (hi0 + q >= 0 && hi0 + q < p.H) mk |= 1u << q;
+        if (wi0 + q >= 0 && wi0 + q < p.W) mk |= 16u << q;
+      }
+    }
+    a_mask[i] = mk;
+  }
+  // weight half-stages: 8 KB each, contiguous in the packed copy, lane l of wave w fetching 16 bytes at 1024 w + 16 l
+  const _Float16 *wpk = p.wtp + (size_t)nt * p.K * WBN + wave * 512 + lane * 8;
+  auto issue_b = [&](int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((gptr_t)wpk, (lptr_t)(Bs + (buf * WBN + 16 * wave) * WROWB), 16, 0, 0);
+    wpk += WBN * WBKE;
+  };
+  // activation super-stages: 64 channels of one tap
+  int s_kh = 0, s_kw = 0, s_c0 = 0;
+  auto issue_a = [&](int buf) __attribute__((always_inline)) {
+    const _Float16 *xa = p.x + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
+      const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16w);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * WBM + 8 * (wave + NW * i)) * AROWB), 16, 0, 0);
+    }
+    if (KS > 1) {
+      if (++s_kw == KS) {
+        s_kw = 0;
+        if (++s_kh == KS) {
+          s_kh = 0;
+          s_c0 += 2 * WBKE;
+        }
+      }
+    } else {
+      s_c0 += 2 * WBKE;
+    }
+  };
+  floatx16 acc_hi[MI], acc_lo[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc_hi[mi][q] = acc_lo[mi][q] = 0.f;
+  auto compute_half = [&](int hs) __attribute__((always_inline)) {   // half-stage hs: super-stage hs / 2, weights hs
+    const char *a_base = As + ((((hs >> 1) & 1) * WBM + wm * 64 + r)) * AROWB;
+    const char *b_base = Bs + ((hs & 1) * WBN + wn * 32 + r) * WROWB;
+    const int half = hs & 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int co = 16 * ((2 * t + h) ^ sw);
+      const int ca = 16 * ((4 * half + 2 * t + h) ^ swa);
+      const halfx8 bh = *reinterpret_cast<const halfx8 *>(b_base + co);
+      const halfx8 bl = *reinterpret_cast<const halfx8 *>(b_base + 64 * WROWB + co);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const halfx8 a = *reinterpret_cast<const halfx8 *>(a_base + mi * 32 * AROWB + ca);
+        acc_hi[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc_hi[mi], 0, 0, 0);
+        acc_lo[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc_lo[mi], 0, 0, 0);
+      }
+    }
+  };
+
+  const int KT = p.K / WBKE;   // half-stages: even, >= 2 (Cin % 64 == 0)
+  issue_a(0);
+  issue_b(0);
+  issue_b(1);
+  for (int hs = 0; hs < KT; ++hs) {
+    __syncthreads();   // vmcnt(0): what half-stage hs needs has landed; everyone has read half-stage hs - 1
+    if (hs >= 1 && hs + 1 < KT) issue_b((hs + 1) & 1);              // into the buffer of half-stage hs - 1
+    if ((hs & 1) == 0 && hs + 2 < KT) issue_a(((hs >> 1) + 1) & 1);   // into the buffer of super-stage hs / 2 - 1
+    __builtin_amdgcn_sched_barrier(0);
+    compute_half(hs);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: 64 output channels at a time, rounds of 128 pixels through a [128][64] float32 transpose
+  // (SPLIT: one channel half, hi + 2^-11 lo; plain: two channel halves, the accumulators as they are)
+  float *Cs = reinterpret_cast<float *>(lds);
+  const int col4 = tid & 15, row0 = tid >> 4;   // 16 float4 per row, 32 rows per pass
+  constexpr int NHALF = SPLIT ? 1 : 2;
+#pragma unroll
+  for (int ch = 0; ch < NHALF; ++ch) {
+  const int n = nt * (SPLIT ? 64 : 128) + 64 * ch + 4 * col4;
+  const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+  for (int rho = 0; rho < 2; ++rho) {
+    float4 rv[4];
+    if (RES != 0) {   // residual of this round's rows: in flight under the two barriers and the transpose
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mr = m0 + 128 * rho + row0 + 32 * i;
+        const int m = mr < p.M ? mr : p.M - 1;
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(p.res + roff);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the stage buffers (first round) / the previous round's rows have been read
+    asm volatile("" ::: "memory");
+    if ((wm >> 1) == rho) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          Cs[((wm & 1) * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 64 + wn * 32 + r] =
+              SPLIT ? acc_hi[mi][q] + acc_lo[mi][q] * kLoScale : (ch == 0 ? acc_hi[mi][q] : acc_lo[mi][q]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + 32 * i;
+      const int m = m0 + 128 * rho + row;
+      if (m < p.M) {
+        float4 v = *reinterpret_cast<const float4 *>(Cs + row * 64 + 4 * col4);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (RES != 0) {
+          v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+        }
+        if (RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        store4(p.y + (size_t)m * p.Cout + n, v);
+      }
+    }
+  }
+  }
+}
+
 template <int KS, bool SPLIT>
 int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
   const dim3 grid(d.mtiles * d.ntiles), block(512);
-#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_wide16_kernel<KS, R, Q, SPLIT>), grid, block, 0, s, d)
+#define DVSG_LAUNCH(R, Q)                                                                           \
+  do {                                                                                              \
+    if (d.arows) hipLaunchKernelGGL((conv_wide16a_kernel<KS, R, Q, SPLIT>), grid, block, 0, s, d);   \
+    else hipLaunchKernelGGL((conv_wide16_kernel<KS, R, Q, SPLIT>), grid, block, 0, s, d);            \
+  } while (0)
   if (relu) {
     if (res == 0) DVSG_LAUNCH(true, 0);
     else if (res == 1) DVSG_LAUNCH(true, 1);
@@ -321,8 +521,10 @@ int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
 
 // Packed weights for the kernel above: [tile of 128 rows][stage][row][chunk position][8 halves]; stage s of a tile is the
 // 32 k the kernel visits s-th (channel chunk outer, taps inner), position c' of row r holds chunk c' ^ ((r >> 2) & 3).
+// order 1 (conv_wide16a_kernel): stage s = half (s & 1) of the 64-channel chunk of super-stage s / 2 (64-channel chunk outer,
+// taps inner).
 __global__ void pack_wide16_kernel(const _Float16 *__restrict__ wt, _Float16 *__restrict__ out, int K, int Cin, int taps,
-                                   size_t nchunks) {
+                                   int order, size_t nchunks) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nchunks) return;
   const int KT = K / WBKE;
@@ -331,7 +533,11 @@ __global__ void pack_wide16_kernel(const _Float16 *__restrict__ wt, _Float16 *__
   const int st = (int)(ts % KT);
   const size_t tile = ts / KT;
   const int chunk = pos ^ ((row >> 2) & 3);
-  const int k = (taps > 1 ? (st % taps) * Cin + (st / taps) * WBKE : st * WBKE) + 8 * chunk;
+  int k0;
+  if (taps == 1) k0 = st * WBKE;
+  else if (order == 0) k0 = (st % taps) * Cin + (st / taps) * WBKE;
+  else k0 = ((st >> 1) % taps) * Cin + ((st >> 1) / taps) * 2 * WBKE + (st & 1) * WBKE;
+  const int k = k0 + 8 * chunk;
   *reinterpret_cast<floatx4 *>(out + i * 8) = *reinterpret_cast<const floatx4 *>(wt + (tile * 128 + row) * K + k);
 }
 
@@ -339,16 +545,20 @@ __global__ void pack_wide16_kernel(const _Float16 *__restrict__ wt, _Float16 *__
 
 int g_wide16_packed = 1;   // dvsg_debug_set_option("wide16_packed", 0): weight stages fetched from the [rows][K] layout
 void set_wide16_packed(int v) { g_wide16_packed = v; }
+int g_wide16_arows = 1;    // dvsg_debug_set_option("wide16_arows", v): 0 = 64-byte activation rows everywhere (conv_wide16_kernel),
+                           // 2 = 128-byte rows for K = 128 too (tests)
+void set_wide16_arows(int v) { g_wide16_arows = v; }
+int wide16_pack_order() { return g_wide16_arows ? 1 : 0; }
 
 size_t wide16_packed_bytes(int rows, int Cin, int ksize) { return (size_t)rows * ksize * ksize * Cin * sizeof(_Float16); }
 
 // wt: `rows` weight rows of K = ksize^2 Cin float16 (stacked hi / lo rows, or plain ones), rows % 128 == 0, Cin % 64 == 0
-int launch_pack_wide16(const void *wt, void *out, int rows, int Cin, int ksize, hipStream_t s) {
+int launch_pack_wide16(const void *wt, void *out, int rows, int Cin, int ksize, int order, hipStream_t s) {
   DVSG_REQUIRE(wt && out && rows % 128 == 0 && Cin % 64 == 0 && (ksize == 1 || ksize == 3), "pack_wide16: bad arguments");
   const int K = ksize * ksize * Cin;
   const size_t nchunks = (size_t)rows * K / 8;
   hipLaunchKernelGGL(pack_wide16_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, static_cast<const _Float16 *>(wt),
-                     static_cast<_Float16 *>(out), K, Cin, ksize * ksize, nchunks);
+                     static_cast<_Float16 *>(out), K, Cin, ksize * ksize, order, nchunks);
   return check_launch("pack_wide16_kernel");
 }
 
@@ -375,7 +585,9 @@ int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
   ConvWide16Dev d;
   d.x = static_cast<const _Float16 *>(p.x); d.wt = static_cast<const _Float16 *>(p.wt);
   d.res = static_cast<const _Float16 *>(p.res); d.bias = p.bias; d.y = static_cast<_Float16 *>(p.y);
-  d.wtp = g_wide16_packed ? static_cast<const _Float16 *>(p.wt_packed) : nullptr;
+  // (K = 128 -- two super-stages -- keeps the 64-byte rows: block 2's conv3 2.48 against 2.55 ms)
+  d.arows = g_wide16_arows && p.wt_packed_a != nullptr && (g_wide16_arows == 2 || p.ksize * p.ksize * p.Cin >= 256);
+  d.wtp = d.arows ? static_cast<const _Float16 *>(p.wt_packed_a) : g_wide16_packed ? static_cast<const _Float16 *>(p.wt_packed) : nullptr;
   d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
   d.stride = p.stride; d.pad = p.pad;
   d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;

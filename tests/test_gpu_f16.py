@@ -181,8 +181,8 @@ def test_f16_fused_block1_kernel_matches_the_unfused_layers(net, B, H, W):
 
 
 def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
-    """conv_gemm_wide16.hip (256 x 128 tiles, 64-byte K stages: what dvsg_conv_gemm_f16s runs for launches of >= 256
-    tiles) forced onto small ragged layers -- M not a multiple of 256, stride 2, residual of the output's shape and the
+    """conv_gemm_wide16.hip (256 x 128 tiles, 32-k weight stages from a packed copy, activation rows of 128 or 64 bytes:
+    what dvsg_conv_gemm_f16s runs for launches of >= 256 tiles) forced onto small ragged layers -- M not a multiple of 256, stride 2, residual of the output's shape and the
     subsampled `shortcut`, no residual, no ReLU -- against float32 math on the unrounded weights, and against the
     128 x 128 kernel (same products; the K order within a layer differs by the stage depth)."""
     import torch
@@ -215,12 +215,16 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
             else:
                 res, res_at = None, None
             outs = {}
-            for thr in (1, 1 << 30):   # wide tiles for everything / never
+            # wide tiles for everything, with 128-byte activation rows (the default of K >= 256, forced for all) / with 64-byte
+            # rows and packed weight stages / with 64-byte rows and the weights from their [rows][K] layout; never wide
+            for key, thr, arows, packed in ((1, 1, 2, 1), ("rows64", 1, 0, 1), ("unpacked", 1, 0, 0), (1 << 30, 1 << 30, 1, 1)):
                 _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", thr)
+                _lib.call("dvsg_debug_set_option", b"wide16_arows", arows)
+                _lib.call("dvsg_debug_set_option", b"wide16_packed", packed)
                 y = torch.full((B, ho, wo, cout), float("nan"), device=dev, dtype=torch.float16)
                 _lib.call("dvsg_conv_gemm_f16s", x.data_ptr(), ws.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else 0,
                           y.data_ptr(), B, h, w, cin, cout, k, stride, relu, res_stride, scratch.data_ptr(), scratch.numel(), st)
-                outs[thr] = y.float()
+                outs[key] = y.float()
             w4 = w32.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
             ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
             if res_at is not None:
@@ -233,8 +237,17 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
             assert float((outs[1] - ref).abs().max()) < 1.2e-3 * scale, case          # float16 rounding of the output
             assert float((outs[1] - outs[1 << 30]).abs().max()) < 1.0e-3 * scale, case   # one float16 ulp of the output
             assert float((outs[1] - outs[1 << 30]).abs().mean()) < 2e-5 * scale, case
+            # packing moves bytes, not sums: the same bits; the 128-byte-row kernel visits a 3x3 layer's K in another order
+            assert torch.equal(outs["rows64"], outs["unpacked"]), case
+            assert float((outs["rows64"] - ref).abs().max()) < 1.2e-3 * scale, case
+            if k == 1:
+                assert torch.equal(outs[1], outs["rows64"]), case
+            else:
+                assert float((outs[1] - outs["rows64"]).abs().max()) < 1.0e-3 * scale, case
     finally:
         _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)
+        _lib.call("dvsg_debug_set_option", b"wide16_arows", 1)
+        _lib.call("dvsg_debug_set_option", b"wide16_packed", 1)
 
 
 @pytest.mark.parametrize("source", ["window", "ring_f32", "ring_u8"])
