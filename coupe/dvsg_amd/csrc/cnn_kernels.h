@@ -37,6 +37,7 @@ struct ConvGemm {
   int relu;
   const void *wt_packed = nullptr;   // kF16, optional: the rows of `wt` packed stage by stage for conv_gemm_wide16.hip (launch_pack_wide16, order 0)
   const void *wt_packed_a = nullptr; // ... in order 1, for its 128-byte-activation-row kernel
+  const void *wt_packed_h = nullptr; // ... in order 2, for its 3x3 stride-1 kernel (a kernel row's taps from one staged run)
   int wsplit = 0;     // kF16: wt is the stacked layout [Cout/64][128][K] (64 hi rows, then 64 lo rows); kF32: wt is
                       // [Cout][K/32][32 hi halves | 32 lo halves] and products are formed from float16 pieces (conv_gemm.hip)
   // optional split-K scratch (small batches): partial-tile slabs and kSplitKMaxTiles zeroed int tickets
@@ -53,7 +54,8 @@ void set_wide16_min_tiles(int v);
 // weights packed for that kernel: every 32-k stage of a 128-row tile contiguous, in the LDS image's chunk order
 size_t wide16_packed_bytes(int rows, int Cin, int ksize);
 int launch_pack_wide16(const void *wt, void *out, int rows, int Cin, int ksize, int order, hipStream_t s);
-void set_wide16_arows(int v);       // diagnostic (dvsg_debug_set_option "wide16_arows")
+void set_wide16_arows(int v);
+void set_wide16_hreuse(int v);      // diagnostic (dvsg_debug_set_option "wide16_hreuse")       // diagnostic (dvsg_debug_set_option "wide16_arows")
 void set_wide16_packed(int v);      // diagnostic (dvsg_debug_set_option "wide16_packed")
 // Zeroes n split-K / stream-K tickets with a KERNEL: a hipMemsetAsync captured into a HIP graph (memset node) did not
 // take effect on the second and later replays of the graph on ROCm 7.2 (tests/test_gpu_cnn.py::test_a_step_replays_...).

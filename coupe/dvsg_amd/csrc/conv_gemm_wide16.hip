@@ -498,6 +498,225 @@ void conv_wide16a_kernel(ConvWide16Dev p) {
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// 3x3, stride 1: the three taps of a kernel ROW from ONE staged run of pixels.  conv_wide16a_kernel stages 256 pixels x
+// 64 channels nine times per 64-channel chunk -- once per tap -- although the taps (kh, 0), (kh, 1), (kh, 2) read the same
+// input row shifted by one pixel.  Here a super-stage is (64-channel chunk, kernel row kh): LDS rows 0..255 hold the
+// pixels m0 .. m0 + 255 (linear NHWC index) of input row ho + kh - 1 at their OWN column, and output pixel p multiplies
+// rows p - 1, p, p + 1 for kw = 0, 1, 2 -- a third of the activation traffic and DMA instructions, six weight half-stages
+// (kw x two 32-k halves) per activation stage.  Consequences:
+//   * a tile computes the 254 pixels m0 + 1 .. m0 + 254 (tiles overlap by two; rows 0 and 255 are only ever neighbours):
+//     the two buffers stay 2 x 32 KB and the workgroup 80 KB, two per CU, at 0.8 % more MFMAs;
+//   * the linear neighbour of a pixel in the first / last column of the image is not its spatial neighbour: those lanes'
+//     fragments are zeroed for kw = 0 / kw = 2 (what the padding would have supplied);
+//   * K order: 64-channel chunk, kh, kw, half (launch_pack_wide16 order 2).
+// ----------------------------------------------------------------------------------------
+constexpr int WHM = WBM - 2;   // output pixels per tile
+
+template <bool RELU, int RES, bool SPLIT = true>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv_wide16h_kernel(ConvWide16Dev p) {
+  constexpr int NW = 8, MI = 2;
+  constexpr int AG = WBM / 8 / NW;    // 4 LDS-DMA instructions (8 rows of 128 bytes each) per wave and super-stage
+  constexpr int AROWB = 2 * WROWB;    // 128
+  constexpr float kLoScale = 1.0f / 2048.0f;
+  __shared__ __attribute__((aligned(16))) char lds[2 * WBM * AROWB + 2 * WBN * WROWB];   // 64 + 16 KiB
+  char *As = lds;
+  char *Bs = lds + 2 * WBM * AROWB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const int sw = (r >> 2) & 3;
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+
+  const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  const int m0 = mt * WHM - 1;   // LDS row i <-> pixel m0 + i; outputs for i = 1 .. 254
+
+  // staging: LDS row `row` of a super-stage (kh) is pixel m0 + row of the image row above / at / below its own
+  int a_pix[AG];         // (b, ho - 1, wo) as one index into [B][H][W] (may be negative: the row above the image)
+  unsigned a_mask[AG];   // bit kh: that image row exists
+  int a_chunk[AG];
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    const int row = 8 * (wave + NW * i) + lrow;
+    a_chunk[i] = 8 * (lpos ^ ((row >> 1) & 7));
+    const int m = m0 + row;
+    const bool in = m >= 0 && m < p.M;
+    const int mm = in ? m : 0;
+    const int wo = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int ho = t % p.Ho;
+    const int b = t / p.Ho;
+    a_pix[i] = (b * p.H + ho - 1) * p.W + wo;
+    unsigned mk = 0;
+    if (in) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (ho - 1 + q >= 0 && ho - 1 + q < p.H) mk |= 1u << q;
+    }
+    a_mask[i] = mk;
+  }
+  const _Float16 *wpk = p.wtp + (size_t)nt * p.K * WBN + wave * 512 + lane * 8;
+  auto issue_b = [&](int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((gptr_t)wpk, (lptr_t)(Bs + (buf * WBN + 16 * wave) * WROWB), 16, 0, 0);
+    wpk += WBN * WBKE;
+  };
+  int s_kh = 0, s_c0 = 0;
+  auto issue_a = [&](int buf) __attribute__((always_inline)) {
+    const _Float16 *xa = p.x + (long)s_kh * p.W * p.Cin + s_c0;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const bool ok = ((a_mask[i] >> s_kh) & 1u) != 0;
+      const void *src = ok ? static_cast<const void *>(xa + ((long)a_pix[i] * p.Cin + a_chunk[i])) : static_cast<const void *>(&g_zero16w);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * WBM + 8 * (wave + NW * i)) * AROWB), 16, 0, 0);
+    }
+    if (++s_kh == 3) {
+      s_kh = 0;
+      s_c0 += 2 * WBKE;
+    }
+  };
+  // fragment rows of this lane: output pixel 64 wm + 32 mi + r reads LDS rows (that) + kw - 1, kept inside the buffer for
+  // the two pixels nobody stores; its byte offset and chunk swizzle per (mi, kw), and whether that neighbour is real
+  const int pr0 = wm * 64 + r;   // (+ 32 mi)
+  unsigned a_zero = 0;   // bit 3 mi + kw: the tap falls outside the image row
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + pr0 + 32 * mi;
+    const int mm = m >= 0 && m < p.M ? m : 0;
+    const int wo = mm % p.Wo;
+    if (wo == 0) a_zero |= 1u << (3 * mi);
+    if (wo == p.W - 1) a_zero |= 4u << (3 * mi);
+  }
+  floatx16 acc_hi[MI], acc_lo[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc_hi[mi][q] = acc_lo[mi][q] = 0.f;
+  // half-stage: activation buffer abuf, tap kw, half of the 64 channels, weight buffer bbuf
+  auto compute_half = [&](int abuf, int kw, int half, int bbuf) __attribute__((always_inline)) {
+    const char *a_base = As + abuf * WBM * AROWB;
+    const char *b_base = Bs + (bbuf * WBN + wn * 32 + r) * WROWB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int co = 16 * ((2 * t + h) ^ sw);
+      const halfx8 bh = *reinterpret_cast<const halfx8 *>(b_base + co);
+      const halfx8 bl = *reinterpret_cast<const halfx8 *>(b_base + 64 * WROWB + co);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int rr = pr0 + 32 * mi + kw - 1;
+        asm volatile("" : "+v"(rr));   // (recomputed every time: hoisted out of the K loop the 24 fragment addresses spill)
+        rr = rr < 0 ? 0 : (rr > WBM - 1 ? WBM - 1 : rr);
+        halfx8 a = *reinterpret_cast<const halfx8 *>(a_base + rr * AROWB + 16 * ((4 * half + 2 * t + h) ^ ((rr >> 1) & 7)));
+        if ((a_zero >> (3 * mi + kw)) & 1u) a = halfx8{0, 0, 0, 0, 0, 0, 0, 0};
+        acc_hi[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc_hi[mi], 0, 0, 0);
+        acc_lo[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc_lo[mi], 0, 0, 0);
+      }
+    }
+  };
+
+  const int NS = 3 * (p.Cin / 64);   // super-stages (64-channel chunk, kh), six half-stages each
+  issue_a(0);
+  issue_b(0);
+  issue_b(1);
+  int hs = 0;
+  const int KT = 6 * NS;
+  for (int S = 0; S < NS; ++S) {
+#pragma unroll
+    for (int sub = 0; sub < 6; ++sub, ++hs) {
+      __syncthreads();   // vmcnt(0): what this half-stage needs has landed; everyone has read the previous one
+      if (hs >= 1 && hs + 1 < KT) issue_b((hs + 1) & 1);
+      if (sub == 0 && S + 1 < NS) issue_a((S + 1) & 1);   // into the buffer of super-stage S - 1
+      __builtin_amdgcn_sched_barrier(0);
+      compute_half(S & 1, sub >> 1, sub & 1, hs & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: as in conv_wide16_kernel, for the tile's rows 1 .. 254
+  float *Cs = reinterpret_cast<float *>(lds);
+  const int col4 = tid & 15, row0 = tid >> 4;
+  constexpr int NHALF = SPLIT ? 1 : 2;
+#pragma unroll
+  for (int ch = 0; ch < NHALF; ++ch) {
+  const int n = nt * (SPLIT ? 64 : 128) + 64 * ch + 4 * col4;
+  const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+  for (int rho = 0; rho < 2; ++rho) {
+    float4 rv[4];
+    if (RES != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mr = m0 + 128 * rho + row0 + 32 * i;
+        const int m = mr < 0 ? 0 : (mr < p.M ? mr : p.M - 1);
+        size_t roff;
+        if (RES == 1) {
+          roff = (size_t)m * p.Cout + n;
+        } else {
+          const int wo = m % p.Wo;
+          const int t = m / p.Wo;
+          const int ho = t % p.Ho;
+          const int b = t / p.Ho;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+        }
+        rv[i] = load4(p.res + roff);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if ((wm >> 1) == rho) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          Cs[((wm & 1) * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 64 + wn * 32 + r] =
+              SPLIT ? acc_hi[mi][q] + acc_lo[mi][q] * kLoScale : (ch == 0 ? acc_hi[mi][q] : acc_lo[mi][q]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + 32 * i;
+      const int pr = 128 * rho + row;
+      const int m = m0 + pr;
+      if (pr >= 1 && pr <= WHM && m < p.M) {
+        float4 v = *reinterpret_cast<const float4 *>(Cs + row * 64 + 4 * col4);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (RES != 0) {
+          v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+        }
+        if (RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        store4(p.y + (size_t)m * p.Cout + n, v);
+      }
+    }
+  }
+  }
+}
+
+template <bool SPLIT>
+int launch_h(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
+  const dim3 grid(d.mtiles * d.ntiles), block(512);
+#define DVSG_LAUNCH(R, Q) hipLaunchKernelGGL((conv_wide16h_kernel<R, Q, SPLIT>), grid, block, 0, s, d)
+  if (relu) {
+    if (res == 0) DVSG_LAUNCH(true, 0);
+    else if (res == 1) DVSG_LAUNCH(true, 1);
+    else DVSG_LAUNCH(true, 2);
+  } else {
+    if (res == 0) DVSG_LAUNCH(false, 0);
+    else if (res == 1) DVSG_LAUNCH(false, 1);
+    else DVSG_LAUNCH(false, 2);
+  }
+#undef DVSG_LAUNCH
+  return check_launch("conv_wide16h_kernel");
+}
+
 template <int KS, bool SPLIT>
 int launch_ks(const ConvWide16Dev &d, bool relu, int res, hipStream_t s) {
   const dim3 grid(d.mtiles * d.ntiles), block(512);
@@ -536,7 +755,11 @@ __global__ void pack_wide16_kernel(const _Float16 *__restrict__ wt, _Float16 *__
   int k0;
   if (taps == 1) k0 = st * WBKE;
   else if (order == 0) k0 = (st % taps) * Cin + (st / taps) * WBKE;
-  else k0 = ((st >> 1) % taps) * Cin + ((st >> 1) / taps) * 2 * WBKE + (st & 1) * WBKE;
+  else if (order == 1) k0 = ((st >> 1) % taps) * Cin + ((st >> 1) / taps) * 2 * WBKE + (st & 1) * WBKE;
+  else {   // order 2 (conv_wide16h_kernel): 64-channel chunk, kh, kw, half
+    const int S = st / 6, sub = st % 6;
+    k0 = ((S % 3) * 3 + (sub >> 1)) * Cin + (S / 3) * 2 * WBKE + (sub & 1) * WBKE;
+  }
   const int k = k0 + 8 * chunk;
   *reinterpret_cast<floatx4 *>(out + i * 8) = *reinterpret_cast<const floatx4 *>(wt + (tile * 128 + row) * K + k);
 }
@@ -545,6 +768,8 @@ __global__ void pack_wide16_kernel(const _Float16 *__restrict__ wt, _Float16 *__
 
 int g_wide16_packed = 1;   // dvsg_debug_set_option("wide16_packed", 0): weight stages fetched from the [rows][K] layout
 void set_wide16_packed(int v) { g_wide16_packed = v; }
+int g_wide16_hreuse = 1;   // dvsg_debug_set_option("wide16_hreuse", 0): 3x3 stride-1 layers through conv_wide16a_kernel
+void set_wide16_hreuse(int v) { g_wide16_hreuse = v; }
 int g_wide16_arows = 1;    // dvsg_debug_set_option("wide16_arows", v): 0 = 64-byte activation rows everywhere (conv_wide16_kernel),
                            // 2 = 128-byte rows for K = 128 too (tests)
 void set_wide16_arows(int v) { g_wide16_arows = v; }
@@ -595,6 +820,13 @@ int launch_conv_wide16(const ConvGemm &p, hipStream_t s) {
   d.K = p.ksize * p.ksize * p.Cin;
   d.mtiles = (int)((M + WBM - 1) / WBM);
   d.ntiles = p.wsplit ? p.Cout / 64 : p.Cout / 128;
+  const bool hreuse = g_wide16_hreuse && p.wt_packed_h != nullptr && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.H == p.Ho && p.W == p.Wo;
+  if (hreuse) {
+    d.wtp = static_cast<const _Float16 *>(p.wt_packed_h);
+    d.mtiles = (int)((M + WHM - 1) / WHM);
+    const int resh = !p.res ? 0 : (p.res_stride == 1 && p.res_H == p.Ho && p.res_W == p.Wo ? 1 : 2);
+    return p.wsplit ? launch_h<true>(d, p.relu != 0, resh, s) : launch_h<false>(d, p.relu != 0, resh, s);
+  }
 #ifdef DVSG_STAMPS
   d.stamp = g_w16_stamp_sel == p.ksize * 100000000 + p.Cin * 10000 + p.Cout;
   if (d.stamp) std::fprintf(stderr, "wide16 stamps: ks %d Cin %d Cout %d M %ld tiles %d x %d res %d relu %d\n", p.ksize, p.Cin, p.Cout, M, d.mtiles, d.ntiles, p.res != nullptr, p.relu);

@@ -35,6 +35,7 @@ struct ConvLayer {
   _Float16 *wt16s = nullptr;  // device, float16 hi / lo pairs [cout/64][128][k*k*cin] (conv_gemm.hip SPLIT; not for conv1)
   _Float16 *wt16p = nullptr;  // device, wt16s packed stage by stage for conv_gemm_wide16.hip (cin % 64 == 0 layers)
   _Float16 *wt16pa = nullptr; // device, the same in the order of its 128-byte-activation-row kernel
+  _Float16 *wt16ph = nullptr; // device, the same in the order of its 3x3 stride-1 kernel (3x3 layers only)
   _Float16 *wt32s = nullptr;  // device, "f32s" pieces [cout][k*k*cin/32][32 hi | 32 lo] (conv_gemm.hip SPLIT, T = float; not for conv1)
   float *bias = nullptr;      // device, [cout] float32
   const void *weights(int prec, bool split) const {
@@ -174,8 +175,15 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
     DVSG_HIP(hipMalloc(&pka, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
     net->allocs.push_back(pka);
     if (int rc = launch_pack_wide16(L->wt16s, pka, 2 * L->cout, L->cin, L->ksize, 1, nullptr)) return rc;
-    DVSG_HIP(hipStreamSynchronize(nullptr));
     L->wt16pa = static_cast<_Float16 *>(pka);
+    if (L->ksize == 3) {
+      void *pkh = nullptr;
+      DVSG_HIP(hipMalloc(&pkh, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
+      net->allocs.push_back(pkh);
+      if (int rc = launch_pack_wide16(L->wt16s, pkh, 2 * L->cout, L->cin, L->ksize, 2, nullptr)) return rc;
+      L->wt16ph = static_cast<_Float16 *>(pkh);
+    }
+    DVSG_HIP(hipStreamSynchronize(nullptr));
   }
   if (int rc = upload(net, wt32s, &L->wt32s)) return rc;
   return upload(net, shift, &L->bias);
@@ -319,6 +327,7 @@ int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int
   if (prec == kF16 && pairs) {
     p.wt_packed = L.wt16p;
     p.wt_packed_a = L.wt16pa;
+    p.wt_packed_h = L.wt16ph;
   }
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
@@ -538,15 +547,20 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
     static void *packed = nullptr;
     static size_t packed_bytes = 0;
     const size_t need = wide16_packed_bytes(2 * Cout, Cin, ksize);
-    if (2 * need > packed_bytes) {
+    if (3 * need > packed_bytes) {
       DVSG_HIP(hipDeviceSynchronize());
       if (packed) DVSG_HIP(hipFree(packed));
       packed = nullptr;
       packed_bytes = 0;
-      DVSG_HIP(hipMalloc(&packed, 2 * need));
-      packed_bytes = 2 * need;
+      DVSG_HIP(hipMalloc(&packed, 3 * need));
+      packed_bytes = 3 * need;
     }
     void *packed_a = static_cast<char *>(packed) + need;
+    if (ksize == 3) {
+      void *packed_h = static_cast<char *>(packed) + 2 * need;
+      if (int rc = launch_pack_wide16(wt, packed_h, 2 * Cout, Cin, ksize, 2, as_stream(stream))) return rc;
+      p.wt_packed_h = packed_h;
+    }
     if (int rc = launch_pack_wide16(wt, packed, 2 * Cout, Cin, ksize, 0, as_stream(stream))) return rc;
     if (int rc = launch_pack_wide16(wt, packed_a, 2 * Cout, Cin, ksize, 1, as_stream(stream))) return rc;
     p.wt_packed = packed;
@@ -779,6 +793,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "wide16_min_tiles") == 0) {
     set_wide16_min_tiles(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "wide16_hreuse") == 0) {
+    set_wide16_hreuse(value);
     return DVSG_OK;
   }
   if (std::strcmp(name, "wide16_arows") == 0) {

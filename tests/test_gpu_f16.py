@@ -193,7 +193,11 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
     scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
     cases = [  # k, stride, cin, cout, B, h, w, residual mode (0 none, 1 same shape, 2 subsampled input-sized), relu
         (3, 1, 64, 64, 3, 21, 29, 1, 1), (3, 2, 128, 128, 2, 23, 31, 0, 1), (1, 1, 256, 128, 5, 9, 13, 1, 0),
-        (1, 1, 64, 256, 2, 37, 41, 2, 1), (3, 1, 256, 256, 1, 16, 16, 1, 1), (1, 1, 512, 64, 7, 5, 3, 0, 1)]
+        (1, 1, 64, 256, 2, 37, 41, 2, 1), (3, 1, 256, 256, 1, 16, 16, 1, 1), (1, 1, 512, 64, 7, 5, 3, 0, 1),
+        # 3x3 stride 1: images narrower than a tile (a tile spans many rows and several images), one-pixel-wide and
+        # one-row images, M = 254 k + 1 (a last tile of one pixel), M < one tile
+        (3, 1, 64, 64, 5, 7, 5, 1, 1), (3, 1, 128, 64, 3, 9, 1, 0, 1), (3, 1, 64, 128, 2, 1, 300, 0, 0), (3, 1, 64, 64, 1, 15, 17, 0, 1),
+        (3, 1, 128, 128, 1, 127, 4, 1, 1), (3, 1, 64, 64, 1, 3, 3, 0, 1), (3, 1, 512, 128, 2, 30, 33, 0, 1)]
     try:
         for k, stride, cin, cout, B, h, w, rmode, relu in cases:
             K = k * k * cin
@@ -217,10 +221,13 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
             outs = {}
             # wide tiles for everything, with 128-byte activation rows (the default of K >= 256, forced for all) / with 64-byte
             # rows and packed weight stages / with 64-byte rows and the weights from their [rows][K] layout; never wide
-            for key, thr, arows, packed in ((1, 1, 2, 1), ("rows64", 1, 0, 1), ("unpacked", 1, 0, 0), (1 << 30, 1 << 30, 1, 1)):
+            # ... and, first, with a 3x3 stride-1 layer's three taps of a kernel row from one staged run (the default there)
+            for key, thr, arows, packed, hreuse in ((1, 1, 2, 1, 1), ("rows128", 1, 2, 1, 0), ("rows64", 1, 0, 1, 0),
+                                                    ("unpacked", 1, 0, 0, 0), (1 << 30, 1 << 30, 1, 1, 1)):
                 _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", thr)
                 _lib.call("dvsg_debug_set_option", b"wide16_arows", arows)
                 _lib.call("dvsg_debug_set_option", b"wide16_packed", packed)
+                _lib.call("dvsg_debug_set_option", b"wide16_hreuse", hreuse)
                 y = torch.full((B, ho, wo, cout), float("nan"), device=dev, dtype=torch.float16)
                 _lib.call("dvsg_conv_gemm_f16s", x.data_ptr(), ws.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else 0,
                           y.data_ptr(), B, h, w, cin, cout, k, stride, relu, res_stride, scratch.data_ptr(), scratch.numel(), st)
@@ -240,14 +247,17 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
             # packing moves bytes, not sums: the same bits; the 128-byte-row kernel visits a 3x3 layer's K in another order
             assert torch.equal(outs["rows64"], outs["unpacked"]), case
             assert float((outs["rows64"] - ref).abs().max()) < 1.2e-3 * scale, case
+            assert float((outs["rows128"] - ref).abs().max()) < 1.2e-3 * scale, case
             if k == 1:
-                assert torch.equal(outs[1], outs["rows64"]), case
+                assert torch.equal(outs[1], outs["rows64"]) and torch.equal(outs["rows128"], outs["rows64"]), case
             else:
                 assert float((outs[1] - outs["rows64"]).abs().max()) < 1.0e-3 * scale, case
+                assert float((outs["rows128"] - outs["rows64"]).abs().max()) < 1.0e-3 * scale, case
     finally:
         _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)
         _lib.call("dvsg_debug_set_option", b"wide16_arows", 1)
         _lib.call("dvsg_debug_set_option", b"wide16_packed", 1)
+        _lib.call("dvsg_debug_set_option", b"wide16_hreuse", 1)
 
 
 @pytest.mark.parametrize("source", ["window", "ring_f32", "ring_u8"])
