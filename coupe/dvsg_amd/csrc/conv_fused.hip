@@ -27,6 +27,8 @@
 #include "cnn_device.h"
 #include "cnn_kernels.h"
 
+#include <type_traits>
+
 namespace dvsg {
 namespace {
 
@@ -626,11 +628,282 @@ void conv3x3_1x1_f16_kernel(ConvFusedF16Dev p) {
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// The float16 fusion again for the stride-1 units of block 1 (Cin = 64: a pixel's channels are one 128-byte line), built
+// around what bounds the kernel above: it is latency-bound -- nine tap stages of 32 KB, each requested one stage (256
+// cycles of MFMA per wave) before it is needed, then per 64 output channels a weight fetch and four barriers; 2.4-2.8 TB/s.
+//   * A kernel ROW's three taps come from ONE staged run of pixels (conv_gemm_wide16.hip, conv_wide16h_kernel): LDS rows
+//     0..127 are pixels m0 .. m0 + 127 of input row ho + kh - 1 at their own column, output pixel i reads rows i - 1, i,
+//     i + 1; a tile computes the 126 pixels in between (tiles overlap by two), edge-column lanes are zeroed.  Three
+//     activation stages of 16 KB per tile instead of nine, each requested three tap stages ahead.
+//   * The weights are one STREAM through a ring of three 16 KB slots, requested two stages ahead and waited for with
+//     counted s_waitcnt (loads retire in order): the nine conv2 taps, then conv3's (and the shortcut's) first groups
+//     while conv2 is still multiplying.
+//   * The opening unit's shortcut operand (the unit's input tile) is fetched under the last kernel row into the activation
+//     buffer the middle row has left.
+//   * 80 KB per workgroup (two activation buffers, three ring slots), two workgroups per CU as before; the transpose runs
+//     in 64-row rounds through the second activation buffer (RES 1) or the third ring slot (RES 3).
+// ----------------------------------------------------------------------------------------
+constexpr int FHM = BM - 2;   // output pixels per tile
+
+template <int RES>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void conv3x3_1x1_f16h_kernel(ConvFusedF16Dev p) {
+  static_assert(RES == 1 || RES == 3, "stride-1 units only");
+  constexpr int NW = 8;
+  constexpr float kLoScale = 1.0f / 2048.0f;
+  constexpr int A0 = 0, A1 = 16384, RING = 32768, SLOT = 16384;
+  __shared__ __attribute__((aligned(16))) char lds[81920];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves: 32 pixels x 32 channels (hi + lo)
+  const int r = lane & 31, h = lane >> 5;
+  const int lrow8 = lane >> 3, lpos = lane & 7;
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  const int m0 = xcd_remap(blockIdx.x, p.mtiles) * FHM - 1;   // LDS row i <-> pixel m0 + i; outputs for i = 1 .. 126
+
+  // ---- staging of an activation stage (kernel row kh): row `row` is pixel m0 + row of the image row above / at / below
+  int a_pix[2], a_chunk[2];
+  unsigned a_mask[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + NW * i) + lrow8;
+    a_chunk[i] = 8 * (lpos ^ ((row >> 1) & 7));
+    const int m = m0 + row;
+    const bool in = m >= 0 && m < p.M;
+    const int mm = in ? m : 0;
+    const int wo = mm % p.Wo;
+    const int t = mm / p.Wo;
+    const int ho = t % p.Ho;
+    const int b = t / p.Ho;
+    a_pix[i] = (b * p.H + ho - 1) * p.W + wo;
+    unsigned mk = 0;
+    if (in) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (ho - 1 + q >= 0 && ho - 1 + q < p.H) mk |= 1u << q;
+    }
+    a_mask[i] = mk;
+  }
+  auto issue_a = [&](int kh, int dst) __attribute__((always_inline)) {
+    const _Float16 *xa = p.x + (long)kh * p.W * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = ((a_mask[i] >> kh) & 1u) != 0;
+      const void *src = ok ? static_cast<const void *>(xa + ((long)a_pix[i] * 64 + a_chunk[i])) : static_cast<const void *>(&g_zero16f);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + dst + 8 * (wave + NW * i) * ROWB), 16, 0, 0);
+    }
+  };
+  // ---- a 16 KB weight stage: 128 stacked rows x 64 k, rows `row_elems` apart in memory, into ring slot `slot`
+  auto issue_w = [&](const _Float16 *src, int row_elems, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 8 * (wave + NW * i) + lrow8;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * row_elems + 8 * (lpos ^ ((row >> 1) & 7))),
+                                       (lptr_t)(lds + RING + slot * SLOT + 8 * (wave + NW * i) * ROWB), 16, 0, 0);
+    }
+  };
+  // stream element q: 0..8 conv2's taps, then conv3's (RES 3: alternating with the shortcut's) groups
+  auto issue_q = [&](int q) __attribute__((always_inline)) {
+    if (q < 9) issue_w(p.wt2 + q * 64, 576, q % 3);
+    else if (RES == 1) issue_w(p.wt3 + (size_t)(q - 9) * 128 * 64, 64, (q - 9) & 1);
+    else if (q == 9) issue_w(p.wt3, 64, 0);
+    else issue_w(p.wts, 64, 1);
+  };
+
+  floatx16 acc_hi, acc_lo;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc_hi[q] = acc_lo[q] = 0.f;
+  // the lane's output pixel and whether its left / right neighbour exists
+  const int pr = wm * 32 + r;
+  bool no_left, no_right;
+  {
+    const int m = m0 + pr;
+    const int mm = m >= 0 && m < p.M ? m : 0;
+    const int wo = mm % p.Wo;
+    no_left = wo == 0;
+    no_right = wo == p.W - 1;
+  }
+  // 64 k of one tap: activation rows shifted by kw - 1 in buffer `abuf`, weights in ring slot `slot`
+  auto mma_tap = [&](int abuf, int kw, int slot) __attribute__((always_inline)) {
+    int rr = pr + kw - 1;
+    asm volatile("" : "+v"(rr));
+    rr = rr < 0 ? 0 : (rr > BM - 1 ? BM - 1 : rr);
+    const bool zero = (kw == 0 && no_left) || (kw == 2 && no_right);
+    const char *a_row = lds + abuf + rr * ROWB;
+    const int swa = (rr >> 1) & 7;
+    const char *b_row = lds + RING + slot * SLOT + (wn * 32 + r) * ROWB;
+    const int swb = (r >> 1) & 7;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      halfx8 a = *reinterpret_cast<const halfx8 *>(a_row + 16 * ((2 * kb + h) ^ swa));
+      if (zero) a = halfx8{0, 0, 0, 0, 0, 0, 0, 0};
+      const halfx8 bh = *reinterpret_cast<const halfx8 *>(b_row + 16 * ((2 * kb + h) ^ swb));
+      const halfx8 bl = *reinterpret_cast<const halfx8 *>(b_row + 64 * ROWB + 16 * ((2 * kb + h) ^ swb));
+      acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc_hi, 0, 0, 0);
+      acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc_lo, 0, 0, 0);
+    }
+  };
+
+  // ---------------------------------------------------------------- phase 1: conv2, nine tap stages
+  issue_a(0, A0);
+  issue_q(0);
+  issue_q(1);
+  auto tap_stage = [&](auto T) __attribute__((always_inline)) {
+    constexpr int t = decltype(T)::value;
+    constexpr int kh = t / 3, kw = t % 3;
+    // the stage's weights (and its activation stage) have landed when only what was requested after them is outstanding:
+    // one weight stage (2 instructions per wave), plus the next activation stage behind taps 1 and 4 (NOT 7: kernel row 2
+    // is the last -- a vmcnt(4) there let tap 7 start on weights still in flight, ~10 tiles in 16 000 at 3840x2160)
+    // (RES 3: and the shortcut's operand behind tap 7)
+    if (t == 1 || t == 4 || (RES == 3 && t == 7)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // visible to all; everyone has read stage t - 1
+    asm volatile("" ::: "memory");
+    if (kw == 0 && kh < 2) issue_a(kh + 1, (kh + 1) & 1 ? A1 : A0);
+    if (RES == 3 && t == 6) {   // the unit's input tile (rows = this tile's pixels) into A1, free since tap 5
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + NW * i) + lrow8;
+        const int mr = m0 + row;
+        const int m = mr < 0 ? 0 : (mr < p.M ? mr : p.M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.res + (size_t)m * CSC + 8 * (lpos ^ ((row >> 1) & 7))),
+                                         (lptr_t)(lds + A1 + 8 * (wave + NW * i) * ROWB), 16, 0, 0);
+      }
+    }
+    issue_q(t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(kh & 1 ? A1 : A0, kw, t % 3);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  tap_stage(std::integral_constant<int, 0>{});
+  tap_stage(std::integral_constant<int, 1>{});
+  tap_stage(std::integral_constant<int, 2>{});
+  tap_stage(std::integral_constant<int, 3>{});
+  tap_stage(std::integral_constant<int, 4>{});
+  tap_stage(std::integral_constant<int, 5>{});
+  tap_stage(std::integral_constant<int, 6>{});
+  tap_stage(std::integral_constant<int, 7>{});
+  tap_stage(std::integral_constant<int, 8>{});
+
+  // ---------------------------------------------------------------- the tile becomes conv3's left operand (float16, in A0)
+  const float bmid = p.bias2[32 * wn + r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // everyone is done with kh = 2's activation stage (A0)
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int R = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    const int k2 = 32 * wn + r;
+    const float v = fmaxf(acc_hi[q] + acc_lo[q] * kLoScale + bmid, 0.f);
+    *reinterpret_cast<_Float16 *>(lds + A0 + R * ROWB + 16 * ((k2 >> 3) ^ ((R >> 1) & 7)) + 2 * (k2 & 7)) = (_Float16)v;
+  }
+
+  // ---------------------------------------------------------------- phase 2: conv3 (+ shortcut), 64 channels at a time
+  float *Cs = reinterpret_cast<float *>(lds + (RES == 1 ? A1 : RING + 2 * SLOT));   // [64][64] float32
+  const int col4 = tid & 15, row0 = tid >> 4;   // 16 float4 per row, 32 rows per pass
+  const int ngroups = p.Cout / 64;
+  for (int g = 0; g < ngroups; ++g) {
+    const int n = 64 * g + 4 * col4;
+    float4 bias4 = *reinterpret_cast<const float4 *>(p.bias3 + n);
+    if (RES == 3) {
+      const float4 bs = *reinterpret_cast<const float4 *>(p.biass + n);
+      bias4.x += bs.x; bias4.y += bs.y; bias4.z += bs.z; bias4.w += bs.w;
+    }
+    float4 rv[2][2];
+    if (RES == 1) {   // residual rows of both rounds: in flight under the MFMAs and the transposes
+#pragma unroll
+      for (int rho = 0; rho < 2; ++rho)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int mr = m0 + 64 * rho + row0 + 32 * i;
+          const int m = mr < 0 ? 0 : (mr < p.M ? mr : p.M - 1);
+          rv[rho][i] = load4(p.res + (size_t)m * p.Cout + n);
+        }
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the four residual loads: the group's weights are in
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc_hi[q] = acc_lo[q] = 0.f;
+    {
+      const int slot = RES == 1 ? (g & 1) : 0;
+      const char *a_row = lds + A0 + (wm * 32 + r) * ROWB;
+      const char *b_row = lds + RING + slot * SLOT + (wn * 32 + r) * ROWB;
+      const int sw = (r >> 1) & 7;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int co = 16 * ((2 * kb + h) ^ sw);
+        const halfx8 a = *reinterpret_cast<const halfx8 *>(a_row + co);
+        acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, *reinterpret_cast<const halfx8 *>(b_row + co), acc_hi, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, *reinterpret_cast<const halfx8 *>(b_row + 64 * ROWB + co), acc_lo, 0, 0, 0);
+      }
+      if (RES == 3) {   // + the shortcut conv of the unit's input tile, in A1
+        const char *x_row = lds + A1 + (wm * 32 + r) * ROWB;
+        const char *s_row = lds + RING + SLOT + (wn * 32 + r) * ROWB;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          const int co = 16 * ((2 * kb + h) ^ sw);
+          const halfx8 a = *reinterpret_cast<const halfx8 *>(x_row + co);
+          acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, *reinterpret_cast<const halfx8 *>(s_row + co), acc_hi, 0, 0, 0);
+          acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, *reinterpret_cast<const halfx8 *>(s_row + 64 * ROWB + co), acc_lo, 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // the group's weight slot(s) have been read; so has the previous group's transpose
+    asm volatile("" ::: "memory");
+    if (RES == 1) {
+      if (g + 2 < ngroups) issue_w(p.wt3 + (size_t)(g + 2) * 128 * 64, 64, g & 1);
+    } else if (g + 1 < ngroups) {
+      issue_w(p.wt3 + (size_t)(g + 1) * 128 * 64, 64, 0);
+      issue_w(p.wts + (size_t)(g + 1) * 128 * 64, 64, 1);
+    }
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      if (rho == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the first round's rows have been read
+        asm volatile("" ::: "memory");
+      }
+      if ((wm >> 1) == rho) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          Cs[((wm & 1) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * 64 + wn * 32 + r] = acc_hi[q] + acc_lo[q] * kLoScale;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 32 * i;
+        const int prow = 64 * rho + row;
+        const int m = m0 + prow;
+        if (prow >= 1 && prow <= FHM && m < p.M) {
+          float4 o = *reinterpret_cast<const float4 *>(Cs + row * 64 + 4 * col4);
+          o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w;
+          if (RES == 1) {
+            o.x += rv[rho][i].x; o.y += rv[rho][i].y; o.z += rv[rho][i].z; o.w += rv[rho][i].w;
+          }
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+          store4(p.y + (size_t)m * p.Cout + n, o);
+        }
+      }
+    }
+  }
+}
+
+int g_fused_hreuse = 1;   // dvsg_debug_set_option("fused_hreuse", 0): block 1's stride-1 units through conv3x3_1x1_f16_kernel
+
 int g_fuse_conv = 1;  // dvsg_debug_set_option("fuse_conv", 0) turns the fused block-1 path off
 
 }  // namespace
 
 void set_fuse_conv(int v) { g_fuse_conv = v; }
+void set_fused_hreuse(int v) { g_fused_hreuse = v; }
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize) {
   if (prec == kF16) return g_fuse_conv != 0 && ksize == 3 && Cmid == CMID && Cin % 64 == 0 && Cout % 64 == 0;
   return g_fuse_conv != 0 && (prec == kF32 || prec == kF32S) && ksize == 3 && Cmid == CMID && Cin % 32 == 0 && Cin >= 64 && Cout % 128 == 0;
@@ -662,6 +935,13 @@ static int launch_conv3x3_1x1_f16(const ConvFused &p, hipStream_t s) {
                  2.0 * (double)M * CMID * (9.0 * p.Cin) + 2.0 * (double)M * p.Cout * CMID + (sc ? 2.0 * (double)M * p.Cout * CSC : 0.0),
                  2.0 * ((double)p.B * p.H * p.W * p.Cin + 2.0 * CMID * 9 * p.Cin + 2.0 * p.Cout * CMID +
                         (sc ? (double)M * CSC + 2.0 * p.Cout * CSC + (double)M * p.Cout : 2.0 * (double)M * p.Cout)));
+  if (g_fused_hreuse && p.stride == 1 && p.Cin == 64 && p.Cout >= 128 && p.H == p.Ho && p.W == p.Wo && (res == 1 || res == 3)) {
+    d.mtiles = (int)((M + FHM - 1) / FHM);
+    const dim3 gridh(d.mtiles), blockh(512);
+    if (res == 1) hipLaunchKernelGGL((conv3x3_1x1_f16h_kernel<1>), gridh, blockh, 0, s, d);
+    else hipLaunchKernelGGL((conv3x3_1x1_f16h_kernel<3>), gridh, blockh, 0, s, d);
+    return check_launch("conv3x3_1x1_f16h_kernel");
+  }
   const dim3 grid(d.mtiles), block(512);
   if (res == 1) hipLaunchKernelGGL((conv3x3_1x1_f16_kernel<1>), grid, block, 0, s, d);
   else if (res == 2) hipLaunchKernelGGL((conv3x3_1x1_f16_kernel<2>), grid, block, 0, s, d);

@@ -795,6 +795,10 @@ int dvsg_debug_set_option(const char *name, int value) {
     set_wide16_min_tiles(value);
     return DVSG_OK;
   }
+  if (std::strcmp(name, "fused_hreuse") == 0) {
+    set_fused_hreuse(value);
+    return DVSG_OK;
+  }
   if (std::strcmp(name, "wide16_hreuse") == 0) {
     set_wide16_hreuse(value);
     return DVSG_OK;

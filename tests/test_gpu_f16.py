@@ -180,6 +180,32 @@ def test_f16_fused_block1_kernel_matches_the_unfused_layers(net, B, H, W):
     assert np.array_equal(F_fused, net.forward(x, precision="f16").cpu().numpy())   # deterministic
 
 
+def test_f16_fused_block1_kernels_agree_at_full_frames(net):
+    """conv3x3_1x1_f16h_kernel (block 1's stride-1 units: a kernel row's three taps from one staged run of pixels, the
+    weights one stream through a three-slot ring behind COUNTED waits) against conv3x3_1x1_f16_kernel on a 3840x2160
+    window, ten runs each unit: the same products in the same order, so bit for bit -- and a wait that lets a tap start on
+    weights still in flight shows here (it did: ~10 wrong tiles of 16 000 per run with vmcnt(4) instead of vmcnt(2) at
+    tap 7, invisible at the small shapes of the test above)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    x = bench.gpu_windows(1, 2160, 3840, 50, torch.device("cuda:0"))
+    try:
+        for stage in (2, 3):      # the opening unit (shortcut fused), the second unit (residual)
+            _lib.call("dvsg_debug_set_option", b"fused_hreuse", 0)
+            ref = net.tap(x, stage, precision="f16").clone()
+            _lib.call("dvsg_debug_set_option", b"fused_hreuse", 1)
+            for rep in range(10):
+                got = net.tap(x, stage, precision="f16")
+                assert torch.equal(got, ref), "stage %d run %d: %d values differ" % (stage, rep, int((got != ref).sum()))
+    finally:
+        _lib.call("dvsg_debug_set_option", b"fused_hreuse", 1)
+
+
 def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
     """conv_gemm_wide16.hip (256 x 128 tiles, 32-k weight stages from a packed copy, activation rows of 128 or 64 bytes:
     what dvsg_conv_gemm_f16s runs for launches of >= 256 tiles) forced onto small ragged layers -- M not a multiple of 256, stride 2, residual of the output's shape and the

@@ -31,12 +31,16 @@ def kclass(name):
         if base == "conv_gemm_kernel":
             li = re.findall(r"Li(\d+)E", s)      # <T, BN, WM, WN, KS, ...>
             return 1 if len(li) >= 4 and li[3] == "3" else 2
-        if base == "conv_wide16_kernel":         # the float16 mode's 256 x 128 tiles: <KS, RELU, RES>
+        if base in ("conv_wide16_kernel", "conv_wide16a_kernel"):   # the float16 mode's 256 x 128 tiles: <KS, RELU, RES>
             li = re.findall(r"Li(\d+)E", s)
             return 1 if li and li[0] == "3" else 2
+        if base == "conv_wide16h_kernel":        # ... their 3x3 stride-1 form
+            return 1
         s = base
-    if s.startswith("conv_wide16_kernel"):
-        m = re.match(r"conv_wide16_kernel<(\d+)", s)
+    if s.startswith("conv_wide16h_kernel"):
+        return 1
+    if s.startswith(("conv_wide16_kernel", "conv_wide16a_kernel")):
+        m = re.match(r"conv_wide16a?_kernel<(\d+)", s)
         return 1 if m and m.group(1) == "3" else 2
     if s.startswith("conv3x3_1x1"):          # block 1's fused conv2 + conv3 (float32 / pieces / float16 kernels)
         return 8
@@ -63,7 +67,7 @@ def kprec(name):
         if base == "conv_gemm_kernel":
             return "f16" if "IDF16_" in s else ("f32s" if s.split("EEv")[0].endswith("Lb1") else "f32")
         return "f16" if "DF16_" in s else None
-    if s.startswith(("conv_wide16_kernel", "conv3x3_1x1_f16_kernel", "conv1_f16_kernel", "maxpool_h8_kernel")) or "_Float16" in s:
+    if s.startswith(("conv_wide16", "conv3x3_1x1_f16_kernel", "conv1_f16_kernel", "maxpool_h8_kernel")) or "_Float16" in s:
         return "f16"
     if s.startswith(("conv1_split_kernel", "maxpool_p_kernel", "avgpool_partial_p_kernel")):
         return "f32s"
