@@ -582,8 +582,10 @@ void conv_gemm_kernel(ConvGemmDev p) {
 
 int g_conv_variant = 0;  // dvsg_debug_set_option("conv_variant", v): 0 = auto, 1 = 4 waves, 2 = 8 waves,
                          // 3 = no split-K, 4 = 64-wide tiles only, 5 = no 256 x 128 float16 tiles, 6 = no stream-K tail
-long g_wide16_min_tiles = 256;   // float16 mode: 256 x 128 tiles from this many of them (half a round of 512 workgroups: measured
-                                 // never slower from there, batch 1 .. 16 at 288p .. 4K; 128 and below lose at batch 1-2)
+long g_wide16_min_tiles = 128;   // float16 mode: 256 x 128 tiles from this many of them (a quarter of a round of 512 workgroups).
+                                 // Round 2 measured 256 (128 and below lost at batch 1-2 with the kernels of then); with packed
+                                 // weight stages, 128-byte activation rows and the 3x3 row reuse 128 is -0.5 % at batch 16, -4.5 %
+                                 // at batch 4 (720p), equal at batch 1; 64 and 32 lose 4-27 % at batch 1-4
 
 template <typename T, int BN, int WM, int WN, int KS, int MODE, bool SPLIT = false>
 int launch_cfg(const ConvGemmDev &d, int blocks, bool relu, int res, hipStream_t s) {

@@ -280,7 +280,7 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
                 assert float((outs[1] - outs["rows64"]).abs().max()) < 1.0e-3 * scale, case
                 assert float((outs["rows128"] - outs["rows64"]).abs().max()) < 1.0e-3 * scale, case
     finally:
-        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 256)
+        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 128)
         _lib.call("dvsg_debug_set_option", b"wide16_arows", 1)
         _lib.call("dvsg_debug_set_option", b"wide16_packed", 1)
         _lib.call("dvsg_debug_set_option", b"wide16_hreuse", 1)
