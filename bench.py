@@ -45,6 +45,9 @@ MFMA_CLASSES = (0, 1, 2, 8)
 KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*>", 2: "conv_gemm_kernel<*,1,*>",
                   3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel",
                   8: "conv3x3_1x1_kernel"}
+# the float16 mode's kernels of the same classes (big launches)
+KERNEL_CLASSES_F16 = {0: "conv1_f16_march_kernel", 1: "conv_wide16h_kernel / conv_wide16a_kernel<3,*>", 2: "conv_wide16a_kernel<1,*> / conv_wide16_kernel<1,*>",
+                      3: "maxpool_h8_kernel", 8: "conv3x3_1x1_f16h_kernel"}
 
 
 def gpu_windows(B, H, W, seed, dev, S=7):
@@ -464,7 +467,7 @@ def main():
         # the profiled unit is one dvsg_stabilize call: CB windows (= B at one GPU, 16 of a rank's 64 at N > 1)
         traffic, traffic_src = pmc_traffic(cls, CB, H, W, args.precision)
         roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "kernel": KERNEL_CLASSES[cls], "launches": launches,
+                         "kernel": (KERNEL_CLASSES_F16.get(cls, KERNEL_CLASSES[cls]) if args.precision == "f16" else KERNEL_CLASSES[cls]), "launches": launches,
                          "avg_launch_ms": total_ms / max(launches, 1),
                          "algorithmic_per_launch": (flops if cls in MFMA_CLASSES else nbytes) / max(launches, 1),
                          "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
