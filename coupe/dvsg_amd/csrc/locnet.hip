@@ -166,22 +166,22 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
   if (int rc = upload(net, wt16, &L->wt16)) return rc;
   if (int rc = upload(net, wt16s, &L->wt16s)) return rc;
   if (L->cin % 64 == 0 && L->cout % 64 == 0) {   // the layers conv_gemm_wide16.hip can take
-    void *pk = nullptr;
-    DVSG_HIP(hipMalloc(&pk, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
-    net->allocs.push_back(pk);
-    if (int rc = launch_pack_wide16(L->wt16s, pk, 2 * L->cout, L->cin, L->ksize, 0, nullptr)) return rc;
-    L->wt16p = static_cast<_Float16 *>(pk);
-    void *pka = nullptr;
-    DVSG_HIP(hipMalloc(&pka, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
-    net->allocs.push_back(pka);
-    if (int rc = launch_pack_wide16(L->wt16s, pka, 2 * L->cout, L->cin, L->ksize, 1, nullptr)) return rc;
-    L->wt16pa = static_cast<_Float16 *>(pka);
-    if (L->ksize == 3) {
-      void *pkh = nullptr;
-      DVSG_HIP(hipMalloc(&pkh, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
-      net->allocs.push_back(pkh);
-      if (int rc = launch_pack_wide16(L->wt16s, pkh, 2 * L->cout, L->cin, L->ksize, 2, nullptr)) return rc;
-      L->wt16ph = static_cast<_Float16 *>(pkh);
+    // packed copies: order 0 (64-byte activation rows), 1 (128-byte rows), 2 (3x3: a kernel row's taps from one run);
+    // a 1x1 layer's K order is the same in 0 and 1: one copy
+    auto pack = [&](int order, _Float16 **out) -> int {
+      void *pk = nullptr;
+      DVSG_HIP(hipMalloc(&pk, wide16_packed_bytes(2 * L->cout, L->cin, L->ksize)));
+      net->allocs.push_back(pk);
+      if (int rc = launch_pack_wide16(L->wt16s, pk, 2 * L->cout, L->cin, L->ksize, order, nullptr)) return rc;
+      *out = static_cast<_Float16 *>(pk);
+      return DVSG_OK;
+    };
+    if (int rc = pack(0, &L->wt16p)) return rc;
+    if (L->ksize == 1) {
+      L->wt16pa = L->wt16p;
+    } else {
+      if (int rc = pack(1, &L->wt16pa)) return rc;
+      if (int rc = pack(2, &L->wt16ph)) return rc;
     }
     DVSG_HIP(hipStreamSynchronize(nullptr));
   }
