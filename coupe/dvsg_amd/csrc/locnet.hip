@@ -541,37 +541,32 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
   p.res_H = (p.Ho - 1) * res_stride + 1; p.res_W = (p.Wo - 1) * res_stride + 1;
   p.res_stride = res_stride;
   p.relu = relu;
-  if (prec == kF16 && wsplit && Cin % 64 == 0 && Cout % 64 == 0 && (ksize == 1 || ksize == 3)) {
-    // the packed copy conv_gemm_wide16.hip prefers, made here on every call (a test entry: the weights may have changed
-    // behind the same pointer) in a buffer that only grows
-    static void *packed = nullptr;
-    static size_t packed_bytes = 0;
-    const size_t need = wide16_packed_bytes(2 * Cout, Cin, ksize);
-    if (3 * need > packed_bytes) {
-      DVSG_HIP(hipDeviceSynchronize());
-      if (packed) DVSG_HIP(hipFree(packed));
-      packed = nullptr;
-      packed_bytes = 0;
-      DVSG_HIP(hipMalloc(&packed, 3 * need));
-      packed_bytes = 3 * need;
-    }
-    void *packed_a = static_cast<char *>(packed) + need;
-    if (ksize == 3) {
-      void *packed_h = static_cast<char *>(packed) + 2 * need;
-      if (int rc = launch_pack_wide16(wt, packed_h, 2 * Cout, Cin, ksize, 2, as_stream(stream))) return rc;
-      p.wt_packed_h = packed_h;
-    }
-    if (int rc = launch_pack_wide16(wt, packed, 2 * Cout, Cin, ksize, 0, as_stream(stream))) return rc;
-    if (int rc = launch_pack_wide16(wt, packed_a, 2 * Cout, Cin, ksize, 1, as_stream(stream))) return rc;
-    p.wt_packed = packed;
-    p.wt_packed_a = packed_a;
-  }
   const size_t cbytes = align256((size_t)kSplitKMaxTiles * sizeof(int));
   if (scratch && scratch_bytes > cbytes) {  // [tickets | partial-tile slabs]
     if (int rc = launch_zero_tickets(static_cast<int *>(scratch), cbytes / sizeof(int), as_stream(stream))) return rc;
     p.splitk_counters = static_cast<int *>(scratch);
     p.splitk_scratch = static_cast<char *>(scratch) + cbytes;
     p.splitk_scratch_bytes = scratch_bytes - cbytes;
+  }
+  if (prec == kF16 && wsplit && Cin % 64 == 0 && Cout % 64 == 0 && (ksize == 1 || ksize == 3) && scratch) {
+    // the packed weight copies conv_gemm_wide16.hip prefers (what dvsg_locnet_create makes once per layer), made here on
+    // every call behind the tickets and the partial-tile slabs when the caller's scratch has room for them; without
+    // them the layer runs from the [rows][K] layout
+    const size_t need = align256(wide16_packed_bytes(2 * Cout, Cin, ksize));
+    const size_t base = cbytes + align256(kSplitKSlabBytes);
+    if (scratch_bytes >= base + 3 * need) {
+      char *pk = static_cast<char *>(scratch) + base;
+      if (int rc = launch_pack_wide16(wt, pk, 2 * Cout, Cin, ksize, 0, as_stream(stream))) return rc;
+      p.wt_packed = pk;
+      if (ksize == 1) {
+        p.wt_packed_a = pk;
+      } else {
+        if (int rc = launch_pack_wide16(wt, pk + need, 2 * Cout, Cin, ksize, 1, as_stream(stream))) return rc;
+        if (int rc = launch_pack_wide16(wt, pk + 2 * need, 2 * Cout, Cin, ksize, 2, as_stream(stream))) return rc;
+        p.wt_packed_a = pk + need;
+        p.wt_packed_h = pk + 2 * need;
+      }
+    }
   }
   return launch_conv_gemm(p, as_stream(stream));
 }

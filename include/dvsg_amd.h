@@ -244,7 +244,10 @@ int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const v
 /* The layer as the float16 network runs it: float16 activations against weights kept as float16
  * hi / lo PAIRS, w ~ hi + 2^-11 lo (hi = f16(w), lo = f16((w - hi) * 2048)), i.e. effectively float32
  * weights at twice the matrix-core work and unchanged activation traffic.  wt_split is
- * [Cout/64][128][K]: for each group of 64 output channels 64 rows of hi, then 64 rows of lo. */
+ * [Cout/64][128][K]: for each group of 64 output channels 64 rows of hi, then 64 rows of lo.
+ * scratch: as for dvsg_conv_gemm_f32 (tickets + 64 MiB of partial-tile slabs); with 3 x (2 Cout K) x 2 more bytes
+ * behind them the call also makes the stage-packed weight copies the network's big launches run from
+ * (dvsg_locnet_create keeps them per layer); otherwise it reads the weights from wt_split as they are: same results. */
 int dvsg_conv_gemm_f16s(const void *x, const void *wt_split, const float *bias, const void *res, void *y,
                         int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
                         int res_stride, void *scratch, size_t scratch_bytes, void *stream);

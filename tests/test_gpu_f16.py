@@ -134,7 +134,7 @@ def test_conv_gemm_f16_layer(net):
         hi = w32.half()
         lo = ((w32 - hi.float()) * 2048.0).half()
         ws = torch.stack([hi.reshape(cout // 64, 64, K), lo.reshape(cout // 64, 64, K)], 1).reshape(2 * cout, K).contiguous()
-        scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(160 << 20, dtype=torch.uint8, device=dev)   # tickets + slabs + room for the packed weight copies
         for Bs in (2, 40):
             xs = (torch.rand((Bs, h, w, cin), generator=g, device=dev) - 0.3).half()
             rs = (torch.rand((Bs, ho, wo, cout), generator=g, device=dev) - 0.5).half()
@@ -216,7 +216,7 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(5)
     st = torch.cuda.current_stream().cuda_stream
-    scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(160 << 20, dtype=torch.uint8, device=dev)   # tickets + slabs + room for the packed weight copies
     cases = [  # k, stride, cin, cout, B, h, w, residual mode (0 none, 1 same shape, 2 subsampled input-sized), relu
         (3, 1, 64, 64, 3, 21, 29, 1, 1), (3, 2, 128, 128, 2, 23, 31, 0, 1), (1, 1, 256, 128, 5, 9, 13, 1, 0),
         (1, 1, 64, 256, 2, 37, 41, 2, 1), (3, 1, 256, 256, 1, 16, 16, 1, 1), (1, 1, 512, 64, 7, 5, 3, 0, 1),

@@ -16,7 +16,7 @@ layers = [tuple(int(t) for t in a.split(",")) for a in sys.argv[3:]] or [
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 st = torch.cuda.current_stream().cuda_stream
-scratch = torch.empty(66 << 20, dtype=torch.uint8, device=dev)
+scratch = torch.empty(160 << 20, dtype=torch.uint8, device=dev)   # tickets + slabs + the packed weight copies
 for k, cin, cout, B, h, w, rmode, relu in layers:
     K = k * k * cin
     x = (torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3).half()
