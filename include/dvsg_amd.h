@@ -325,7 +325,11 @@ int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, c
                          const float *res, float *y, int B, int H, int W, int Cin, int Cout, int stride, int res_stride,
                          void *stream);
 
-/* Diagnostic A/B switches for kernel experiments ("conv_variant", "conv1_variant", "fuse_conv", "fuse_shortcut", "f16_split").  Process-global. */
+/* Diagnostic A/B switches for kernel experiments, process-global: "conv_variant", "conv1_variant", "fuse_conv",
+ * "fuse_shortcut", "f16_split", "f16_pair_mask", and for the float16 mode's big launches "wide16_min_tiles" (tiles from
+ * which the 256 x 128 geometry runs: 128), "wide16_packed" / "wide16_arows" / "wide16_hreuse" / "fused_hreuse" (1: weight
+ * stages from the packed copy, 128-byte activation rows, a 3x3 kernel row's taps from one staged run, the same in block 1's
+ * fused kernel; 0 selects the kernel each replaced).  Results do not depend on them beyond float32 re-association. */
 int dvsg_debug_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------
