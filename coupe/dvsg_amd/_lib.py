@@ -60,6 +60,12 @@ SIGNATURES = {
     "dvsg_stabilize_ring_u8": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_locnet_forward_ring": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, ctypes.POINTER(_i), _vp,
                                  ctypes.c_size_t, _vp],
+    "dvsg_random_mask_plane_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "dvsg_stabilize_masked_f32": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_stabilize_ring_masked_f32": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_stabilize_ring_masked_u8": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "dvsg_locnet_forward_masked": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, ctypes.POINTER(_i),
+                                   _vp, ctypes.c_size_t, _vp],
     "dvsg_frames_f32_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_frames_f64_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_debug_set_option": [ctypes.c_char_p, _i],

@@ -12,7 +12,8 @@
   (RCCL over xGMI on GPUs; any torch.distributed backend works -- the CPU tests use gloo).
 * `stabilize_clip_teacher_forced` is the reference's other driver, eval_train.py:115-165, whose
   history frames come from the ground-truth stable clip: its windows ARE independent, so a clip
-  runs batched and sharded over the GPUs of a node.
+  runs batched and sharded over the GPUs of a node.  That driver evaluates eval_train.py's OWN graph
+  (:25-51), whose CNN input is multiplied by a random projective mask (:43-45, 53-64): `mask_H`.
 """
 import numpy as np
 import torch
@@ -56,7 +57,16 @@ def sharded_map(n, batch, produce, frame_shape, like, group=None, dst=0):
     # creates the communicator; otherwise the behaviour is undefined and can hang).  The all-reduce creates the
     # communicator with everybody present and doubles as a consistency check of the sharding: the shard sizes
     # the ranks computed must add up to n.
-    count = torch.tensor([local.shape[0]], dtype=torch.int64, device="cpu" if (on_host or not local.is_cuda) else back)
+    # (its device follows the BACKEND, not `local`: a rank with an empty shard may hold a CPU `like` while the populated
+    # ranks hold device tensors, and a CPU tensor in an NCCL / RCCL collective raises on that rank and hangs the others)
+    if dist.get_backend(group) == "nccl":
+        count_dev = torch.device("cuda", torch.cuda.current_device())
+        if not local.is_cuda:
+            local = local.to(count_dev)
+            back = count_dev
+    else:
+        count_dev = torch.device("cpu")
+    count = torch.tensor([local.shape[0]], dtype=torch.int64, device=count_dev)
     dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
     if int(count.item()) != n:
         raise RuntimeError("sharded_map: the ranks hold %d units in total, expected %d (every rank must pass the "
@@ -242,8 +252,25 @@ def _frames_to_pool(fr, pool, h, w, flip, what):
         raise TypeError("%s frames must be uint8 or floating point, got %s" % (what, fr.dtype))
 
 
+def _mask_homographies(mask_H, n, dev):
+    """eval_train.py:55-57 for the n steps of a clip: [n,8] float32 on `dev`, or None (no mask)."""
+    from .model import draw_random_H
+    if mask_H is None:
+        return None
+    if isinstance(mask_H, str):
+        if mask_H != "random":
+            raise ValueError("mask_H must be None, 'random', a torch.Generator or an [N-32,8] array")
+        return draw_random_H(n, dev)
+    if isinstance(mask_H, torch.Generator):
+        return draw_random_H(n, dev, mask_H)
+    Ht = torch.as_tensor(np.asarray(mask_H, dtype=np.float32) if not isinstance(mask_H, torch.Tensor) else mask_H)
+    if tuple(Ht.shape) != (n, 8):
+        raise ValueError("mask_H must be [%d,8] (one homography per stabilised frame), got %s" % (n, tuple(Ht.shape)))
+    return Ht.to(dev, torch.float32).contiguous()
+
+
 def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length=SKIP_LENGTH, channel_order="rgb",
-                                  as_uint8=False, group=None, dst=0):
+                                  as_uint8=False, group=None, dst=0, mask_H="random"):
     """eval_train.py:115-165 for one pair of clips: every unstable frame k >= 32 is stabilised from
     the window [stable k-32, k-16, k-8, k-4, k-2, k-1 | unstable k].  The windows are independent,
     so they run in batches of `batch` and -- with torch.distributed initialised -- shard over the
@@ -251,10 +278,23 @@ def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length
     `dst` (BASELINE.json configs[3]).  Every rank passes the same clips (frame formats as in
     `stabilize_clip`) and keeps the whole pool in its HBM.
 
+    mask_H: eval_train.py evaluates its OWN graph (:25-51, :86), in which the six history frames the CNN sees
+    are multiplied by `random_mask` (:43-45, 53-64) -- a fresh random near-identity homography per `sess.run`.
+      * "random" (default: what eval_train.py does) -- drawn with torch.rand per step (other VALUES than
+        tf.random_uniform would give, the same distribution); a `torch.Generator` -- the same, reproducibly
+        (a CPU generator seeded alike on every rank gives every rank the same table);
+      * an array [N-32,8] -- the homography of each step, AFTER the scale / identity offset of :56-57 (the parity
+        tests pin the loop against the oracle this way);
+      * None -- no mask: model.py's graph (model.py:98-123) on the teacher-forced windows.  NOT what eval_train.py
+        computes; kept for callers that want the regressor's unmasked prediction on ground-truth history.
+    The mask is ONE [b,h,w] plane per batch (`dvsg_random_mask_plane_f32`), multiplied into the history channels
+    inside conv1's load stage (`dvsg_stabilize_ring_masked_{f32,u8}`); the warp samples the unmasked frame (:48).
+
     Returns [N-32,h,w,3] float32 (or uint8 with as_uint8) on rank `dst` -- NumPy if the clips were
     NumPy -- and None on the other ranks."""
     from . import _lib
     from ._tensor import device, ptr, stream
+    from .networks import random_mask_plane
     if channel_order not in ("rgb", "bgr"):
         raise ValueError("channel_order must be 'rgb' or 'bgr'")
     if model.locnet is None:
@@ -270,6 +310,7 @@ def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length
     _check_window(model, S)
     span = int(skip_length[-1])
     table = torch.from_numpy(teacher_forced_index_table(N, skip_length)).to(dev)
+    Ht = _mask_homographies(mask_H, N - span, dev)
     if un.dtype == torch.uint8 and st.dtype == torch.uint8 and tuple(un.shape[1:3]) == (h, w) and not flip:
         pool = torch.cat([un, st], 0)        # the raw frames ARE the ring: 3 bytes per pixel in HBM
     else:
@@ -283,7 +324,8 @@ def stabilize_clip_teacher_forced(model, unstable, stable, batch=16, skip_length
         out = torch.empty((b, h, w, 3), dtype=torch.float32, device=dev)
         # windows b0..b1 straight from the pool (uint8 when the clips came as same-size RGB uint8 frames: the / 255. of
         # eval_train.py's frame reader happens in conv1's load stage); u_t of window k is pool frame table[k, 6] = k + 32
-        model.locnet.stabilize_ring(pool, table[b0:b1], out, F[:b], precision=model.precision)
+        plane = random_mask_plane(Ht[b0:b1], h, w) if Ht is not None else None      # eval_train.py:43 (one plane per window)
+        model.locnet.stabilize_ring(pool, table[b0:b1], out, F[:b], precision=model.precision, mask=plane)
         if not as_uint8:
             return out
         out8 = torch.empty((b, h, w, 3), dtype=torch.uint8, device=dev)

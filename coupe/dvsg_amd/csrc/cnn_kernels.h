@@ -54,8 +54,8 @@ void set_wide16_min_tiles(int v);
 // weights packed for that kernel: every 32-k stage of a 128-row tile contiguous, in the LDS image's chunk order
 size_t wide16_packed_bytes(int rows, int Cin, int ksize);
 int launch_pack_wide16(const void *wt, void *out, int rows, int Cin, int ksize, int order, hipStream_t s);
-void set_wide16_arows(int v);
-void set_wide16_hreuse(int v);      // diagnostic (dvsg_debug_set_option "wide16_hreuse")       // diagnostic (dvsg_debug_set_option "wide16_arows")
+void set_wide16_arows(int v);       // diagnostic (dvsg_debug_set_option "wide16_arows")
+void set_wide16_hreuse(int v);      // diagnostic (dvsg_debug_set_option "wide16_hreuse")
 void set_wide16_packed(int v);      // diagnostic (dvsg_debug_set_option "wide16_packed")
 // Zeroes n split-K / stream-K tickets with a KERNEL: a hipMemsetAsync captured into a HIP graph (memset node) did not
 // take effect on the second and later replays of the graph on ROCm 7.2 (tests/test_gpu_cnn.py::test_a_step_replays_...).
@@ -114,6 +114,8 @@ struct Conv1Src {
   const void *base;   // window tensor, or frame pool
   const int *table;   // ring: [B,7] pool indices (device); an index outside [0, n_pool) stages zeros
   int n_pool;
+  const float *mask = nullptr;   // optional [B,H,W]: eval_train.py:43-45,53-64 -- the 18 history channels of window b are multiplied
+                                 // by mask[b] (one plane: the warp of an all-ones image is the same in every channel) in the load stage
 };
 int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *wt1, const void *wt1h, const void *wt1s,
                  const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);

@@ -49,7 +49,11 @@ constexpr int C1_LDC = 68;                                    // epilogue tile r
 // with -ffp-contract=off); element e is raw channel (e - 1) mod 21 of its pixel, group g = c / 7 lands in
 // output group 2 - g and gets that group's mean; elements outside the image are 0 in the SCALED domain.
 // ----------------------------------------------------------------------------------------
-template <int NT, int GROUPS, bool ALIGNED>
+// MASKED (eval_train.py:43-45, 53-64: `patches * mask` in front of the CNN): src.mask is ONE plane [B,H,W] -- the projective
+// warp of an all-ones image is the same in each of the 18 history channels -- and the raw value of a staged element of
+// channel c < 18 is multiplied by its pixel's mask value before the scale: (x * m) * 255 - mean, three roundings like the
+// TF ops.  The four elements of a group belong to at most two neighbouring pixels: two mask loads per group and row.
+template <int NT, int GROUPS, bool ALIGNED, bool MASKED = false>
 struct Conv1Row {
   static constexpr bool kRing = false;
   typedef float floatx4_u __attribute__((ext_vector_type(4), aligned(4)));
@@ -61,11 +65,16 @@ struct Conv1Row {
                            // 1.5 VALU per element where the masked path spends ~7 (SQ_INSTS_VALU: 10 per MFMA in the f16 kernel)
   struct Data {            // one input row in flight (prefetched under the MFMAs of the rows before it)
     floatx4 reg[GROUPS];
+    float m0[MASKED ? GROUPS : 1], m1[MASKED ? GROUPS : 1];   // mask values of the group's first / second pixel
     bool row_ok;
   };
   const float *img;      // window b
   long row_elems;
   int H;
+  const float *mplane;   // MASKED: mask plane of window b
+  int mW;
+  int mcol0[MASKED ? GROUPS : 1], mcol1[MASKED ? GROUPS : 1];   // columns (clamped into the row) of the group's two pixels
+  unsigned m_first, m_second;   // per element: multiplied by m0 / by m1 (neither: channel >= 18, or not an element of the row)
 
   __device__ __forceinline__ void init(const Conv1Src &src, int tid, int b, int wo0, int H_, int W, int seg_elems) {
     H = H_;
@@ -73,11 +82,30 @@ struct Conv1Row {
     img = static_cast<const float *>(src.base) + (long)b * H * row_elems;
     const long seg0 = (long)(2 * wo0 - 3) * kConv1Cin - 1;
     col_ok = full = 0;
+    if constexpr (MASKED) {
+      mplane = src.mask + (long)b * H * W;
+      mW = W;
+      m_first = m_second = 0;
+    }
     bool mine = true;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       const int e0 = 4 * (tid + NT * i);
       unsigned m = 0;
+      if constexpr (MASKED) {
+        const long ge0 = seg0 + e0;
+        const int c0 = (int)(ge0 >= 0 ? ge0 / kConv1Cin : -((-ge0 + kConv1Cin - 1) / kConv1Cin));   // floor
+        mcol0[i] = c0 < 0 ? 0 : (c0 >= W ? W - 1 : c0);
+        mcol1[i] = c0 + 1 < 0 ? 0 : (c0 + 1 >= W ? W - 1 : c0 + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long ge = ge0 + j;
+          if (ge < 0 || ge >= row_elems) continue;
+          const int col = (int)(ge / kConv1Cin), ch = (int)(ge - (long)col * kConv1Cin);
+          if (ch >= kConv1Cin - 3) continue;                     // the newest frame is never masked (eval_train.py:62)
+          if (col == c0) m_first |= 1u << (4 * i + j); else m_second |= 1u << (4 * i + j);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int e = e0 + j;
@@ -99,6 +127,14 @@ struct Conv1Row {
     d.row_ok = hi >= 0 && hi < H;
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const float *xrow = img + (long)hc * row_elems;
+    if constexpr (MASKED) {
+      const float *mrow = mplane + (long)hc * mW;
+#pragma unroll
+      for (int i = 0; i < GROUPS; ++i) {
+        d.m0[i] = mrow[mcol0[i]];
+        d.m1[i] = mrow[mcol1[i]];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       if constexpr (ALIGNED) {
@@ -113,14 +149,22 @@ struct Conv1Row {
   }
   // group i of a row in flight, scaled
   __device__ __forceinline__ floatx4 scaled(const Data &d, int i) const {
+    floatx4 x = d.reg[i];
+    if constexpr (MASKED) {   // patches * mask (eval_train.py:64), then scale_RGB; a factor of 1.0f is exact
+      floatx4 m4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        m4[j] = ((m_first >> (4 * i + j)) & 1u) ? d.m0[i] : (((m_second >> (4 * i + j)) & 1u) ? d.m1[i] : 1.0f);
+      x = x * m4;
+    }
     if (fast) {   // (both conditions are uniform over the wave / the workgroup)
       if (!d.row_ok) return floatx4{0.f, 0.f, 0.f, 0.f};
-      return d.reg[i] * 255.0f + nmean[i];
+      return x * 255.0f + nmean[i];
     }
     const unsigned ok = d.row_ok ? col_ok : 0u;
     floatx4 v;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? d.reg[i][j] * 255.0f + nmean[i][j] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = ((ok >> (4 * i + j)) & 1u) ? x[j] * 255.0f + nmean[i][j] : 0.f;
     return v;
   }
 };
@@ -145,7 +189,11 @@ constexpr int C1_RING_PX = 2 * (C1_TILE - 1) + 7;            // 261 pixels of th
 constexpr int C1_RING_RG = (3 * (C1_RING_PX + 1) + 3) / 4;   // 197 groups of four per frame: one pixel of lead-in + the run
 constexpr int C1_RING_GROUPS = 7 * C1_RING_RG;               // 1379
 
-template <int NT, int GROUPS, typename TS, bool ALIGNED>
+// MASKED: as for Conv1Row -- the groups of the six history frames (window slots 0..5) multiply their raw values by the mask
+// plane's value at their pixel.  uint8 frames then need x = float32(v / 255.) itself (eval_train.py:119: the frame
+// reader's float64 quotient, rounded once by the feed): q = v * r, q' = fma(fma(-q, 255, v), r, q) with r = f32(1 / 255) is
+// that value for all 256 bytes (exhaustive: tests/test_frames_cpu.py), and (x * 1.0f) * 255.f == (float)v exactly.
+template <int NT, int GROUPS, typename TS, bool ALIGNED, bool MASKED = false>
 struct Conv1RingRow {
   static constexpr bool kRing = true;
   static constexpr bool kU8 = sizeof(TS) == 1;
@@ -162,11 +210,16 @@ struct Conv1RingRow {
   struct Data {            // one input row in flight
     floatx4 regf[kU8 ? 1 : GROUPS];
     unsigned regu[kU8 ? GROUPS : 1];
+    float m0[MASKED ? GROUPS : 1], m1[MASKED ? GROUPS : 1];
     bool row_ok;
   };
   const TS *pool;
   long row_elems;
   int H;
+  const float *mplane;   // MASKED: mask plane of window b
+  int mW;
+  int mcol0[MASKED ? GROUPS : 1], mcol1[MASKED ? GROUPS : 1];
+  unsigned m_first, m_second;   // per element: multiplied by m0 / m1 (a group of the newest frame: neither)
 
   __device__ __forceinline__ void init(const Conv1Src &src, int tid, int b, int wo0, int H_, int W, int /*seg_elems*/) {
     H = H_;
@@ -175,6 +228,11 @@ struct Conv1RingRow {
     const long frame_elems = (long)H * row_elems;
     const long r_first = (long)(2 * wo0 - 4) * 3;    // one pixel before the segment: a multiple of 4
     col_ok = st_ok = phase = no_frame = 0;
+    if constexpr (MASKED) {
+      mplane = src.mask + (long)b * H * W;
+      mW = W;
+      m_first = m_second = 0;
+    }
     bool mine = true;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
@@ -185,6 +243,19 @@ struct Conv1RingRow {
       const bool frame_ok = fi >= 0 && fi < src.n_pool;
       const long r0 = r_first + 4 * g;
       unsigned mc = 0, ms = 0;
+      if constexpr (MASKED) {
+        const int c0 = (int)(r0 >= 0 ? r0 / 3 : -((-r0 + 2) / 3));   // floor: the group's first pixel
+        mcol0[i] = c0 < 0 ? 0 : (c0 >= W ? W - 1 : c0);
+        mcol1[i] = c0 + 1 < 0 ? 0 : (c0 + 1 >= W ? W - 1 : c0 + 1);
+        if (in_range && f < 6) {                                      // eval_train.py:58,62: the history frames only
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const long r = r0 + j;
+            if (r < 0 || r >= row_elems) continue;
+            if ((int)(r / 3) == c0) m_first |= 1u << (4 * i + j); else m_second |= 1u << (4 * i + j);
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int t = 4 * g + j;                      // element of the run, lead-in pixel included
@@ -215,6 +286,14 @@ struct Conv1RingRow {
     d.row_ok = hi >= 0 && hi < H;
     const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi);
     const long roff = (long)hc * row_elems;
+    if constexpr (MASKED) {
+      const float *mrow = mplane + (long)hc * mW;
+#pragma unroll
+      for (int i = 0; i < GROUPS; ++i) {
+        d.m0[i] = mrow[mcol0[i]];
+        d.m1[i] = mrow[mcol1[i]];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
       const TS *p = pool + off[i] + roff;
@@ -249,7 +328,23 @@ struct Conv1RingRow {
     for (int i = 0; i < GROUPS; ++i) {
       const int ph = (phase >> (2 * i)) & 3u;
       floatx4 raw4;
-      if constexpr (kU8) {
+      if constexpr (MASKED) {
+        floatx4 m4, x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          m4[j] = ((m_first >> (4 * i + j)) & 1u) ? d.m0[i] : (((m_second >> (4 * i + j)) & 1u) ? d.m1[i] : 1.0f);
+        if constexpr (kU8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = (float)((d.regu[i] >> (8 * j)) & 255u);
+            const float q = v * (1.0f / 255.0f);
+            x[j] = __builtin_fmaf(__builtin_fmaf(-q, 255.0f, v), 1.0f / 255.0f, q);   // f32(v / 255.), correctly rounded
+          }
+        } else {
+          x = d.regf[i];
+        }
+        raw4 = (x * m4) * 255.0f;
+      } else if constexpr (kU8) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) raw4[j] = (float)((d.regu[i] >> (8 * j)) & 255u);   // == f32(v / 255.) * 255.f, exactly
       } else {
@@ -273,11 +368,20 @@ struct Conv1RingRow {
 };
 
 // SRC of the conv1 kernels: bit 0 = rows on the 16-byte (4-byte for uint8) grid; 0/1 window tensor, 2/3 float32 frame
-// ring, 4/5 uint8 frame ring.
+// ring, 4/5 uint8 frame ring; + 8: the history channels are multiplied by src.mask (eval_train.py's graph).
 template <int NT, int GROUPS, int SRC>
 struct Conv1RowSel {
-  typedef Conv1Row<NT, GROUPS, (SRC & 1) != 0> type;
+  static_assert((SRC & 6) == 0, "ring sources are specialised below");
+  typedef Conv1Row<NT, GROUPS, (SRC & 1) != 0, (SRC & 8) != 0> type;
 };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 10> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, float, false, true> type; };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 11> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, float, true, true> type; };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 12> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, uint8_t, false, true> type; };
+template <int NT, int GROUPS>
+struct Conv1RowSel<NT, GROUPS, 13> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, uint8_t, true, true> type; };
 template <int NT, int GROUPS>
 struct Conv1RowSel<NT, GROUPS, 2> { typedef Conv1RingRow<NT, (C1_RING_GROUPS + NT - 1) / NT, float, false> type; };
 template <int NT, int GROUPS>
@@ -1478,12 +1582,12 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
   const dim3 grid((unsigned)blocks);
   // rows that start on 16-byte boundaries (4-byte for uint8 frames): the staged segment then consists of whole aligned groups
   const bool aligned = W % 4 == 0 && reinterpret_cast<uintptr_t>(src.base) % (src_kind == kSrcRingU8 ? 4 : 16) == 0;
-  const int SRC = 2 * src_kind + (aligned ? 1 : 0);
+  const int SRC = 2 * src_kind + (aligned ? 1 : 0) + (src.mask ? 8 : 0);
   // the f32s activations are float16 pieces (P format): only conv1_split_kernel writes them, whatever the A/B switch says
   // (the float32 kernel's output would be read back as pieces: silent garbage)
   if (out_prec == kF32S && !wt1s) return fail(DVSG_ERR_UNSUPPORTED, "conv1: the f32s precision needs the piece weights");
 #define DVSG_K_F32(SRC) conv1_kernel<4, float, SRC>
-#define DVSG_K_F16(SRC) conv1_f16_kernel<_Float16, SRC>
+#define DVSG_K_F16(SRC) conv1_f16_kernel<_Float16, (SRC) & 7>   /* A/B kernel: never launched with a mask */
 #define DVSG_K_SPLIT(SRC) conv1_split_kernel<float, SRC>
 #define DVSG_C1(KERNEL, NTHREADS, WPTR, YPTR)                                                                            \
   do {                                                                                                                   \
@@ -1493,15 +1597,22 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
       case 2: hipLaunchKernelGGL((KERNEL(2)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
       case 3: hipLaunchKernelGGL((KERNEL(3)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
       case 4: hipLaunchKernelGGL((KERNEL(4)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
-      default: hipLaunchKernelGGL((KERNEL(5)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 5: hipLaunchKernelGGL((KERNEL(5)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 8: hipLaunchKernelGGL((KERNEL(8)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 9: hipLaunchKernelGGL((KERNEL(9)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 10: hipLaunchKernelGGL((KERNEL(10)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 11: hipLaunchKernelGGL((KERNEL(11)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      case 12: hipLaunchKernelGGL((KERNEL(12)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
+      default: hipLaunchKernelGGL((KERNEL(13)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
     }                                                                                                                    \
   } while (0)
   if (out_prec == kF32S) {
     DVSG_C1(DVSG_K_SPLIT, 256, static_cast<const _Float16 *>(wt1s), static_cast<float *>(y));
-  } else if (out_prec == kF16 && wt1h && g_conv1_variant == 3) {   // A/B: one output row per workgroup
+  } else if (out_prec == kF16 && wt1h && g_conv1_variant == 3 && !src.mask) {   // A/B: one output row per workgroup
     DVSG_C1(DVSG_K_F16, 256, static_cast<const _Float16 *>(wt1h), static_cast<_Float16 *>(y));
-  } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2 && g_conv1_variant != 4 &&
-             (g_conv1_variant == 5 || march_bands(B, Ho, wtiles, nullptr) > 0)) {
+  } else if (out_prec == kF16 && wt1h && g_conv1_variant != 2 && g_conv1_variant != 4 && !src.mask &&
+             (g_conv1_variant == 5 || march_bands(B, Ho, wtiles, nullptr) > 0)) {   // (a masked window -- eval_train.py's
+    // graph -- takes the two-row kernel below: same products in the same order)
     // big launches: marching, wave-specialised workgroups (conv1_f16_march_kernel), one per CU
     // (conv1_variant 5 forces it at any size, bands of <= 3 quads: the parity tests run it on small frames)
     int qpb = 0;
@@ -1533,13 +1644,19 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
       case 2: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 2>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
       case 3: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 3>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
       case 4: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 4>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
-      default: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 5>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 5: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 5>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 8: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 8>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 9: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 9>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 10: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 10>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 11: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 11>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      case 12: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 12>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
+      default: hipLaunchKernelGGL((conv1_f16_pair_kernel<_Float16, 13>), pgrid, dim3(256), 0, s, src, wp, bias, yp, H, W, Ho, Wo, wtiles, hpairs); break;
     }
   } else if (out_prec == kF16) {  // conv1_variant 2: f32 multiply, f16 output (window tensors only)
-    DVSG_REQUIRE(src_kind == kSrcWindow, "conv1: conv1_variant 2 takes a window tensor");
+    DVSG_REQUIRE(src_kind == kSrcWindow && !src.mask, "conv1: conv1_variant 2 takes an unmasked window tensor");
     hipLaunchKernelGGL((conv1_kernel<4, _Float16, 0>), grid, dim3(256), 0, s, src, wt1, bias, static_cast<_Float16 *>(y), H, W,
                        Ho, Wo, wtiles);
-  } else if (g_conv1_variant != 0 && src_kind == kSrcWindow) {
+  } else if (g_conv1_variant != 0 && src_kind == kSrcWindow && !src.mask) {
     hipLaunchKernelGGL((conv1_kernel<8, float, 0>), grid, dim3(512), 0, s, src, wt1, bias, static_cast<float *>(y), H, W, Ho,
                        Wo, wtiles);
   } else {

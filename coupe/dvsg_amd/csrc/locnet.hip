@@ -483,16 +483,20 @@ int forward(const dvsg_locnet *net, int prec, const float *patches, int B, int H
                  workspace_bytes, s);
 }
 
-int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const float *u_t, int B, int H, int W,
-              float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
+int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const float *u_t, const float *mask, int B, int H,
+              int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
               void *stream) {
   DVSG_REQUIRE(net && patches_t && u_t && s_t_pred && workspace, "dvsg_stabilize: NULL pointer");
   DVSG_REQUIRE(B > 0 && B <= 65535, "dvsg_stabilize: B=%d out of range", B);
+  DVSG_REQUIRE(prec == kF32 || prec == kF16 || prec == kF32S, "dvsg_stabilize: unknown precision %d", prec);
+  DVSG_REQUIRE(!mask || net->c_in == 21, "dvsg_stabilize_masked: the mask covers the 18 history channels of a 7-frame window");
   const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
   if (ws.total > workspace_bytes)
     return fail(DVSG_ERR_WORKSPACE, "dvsg_stabilize: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
   float *F = F_t ? F_t : ws.Ft;
-  if (int rc = forward(net, prec, patches_t, B, H, W, F, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
+  Conv1Src src{patches_t, nullptr, 0};
+  src.mask = mask;   // eval_train.py:43-45: the CNN sees patches * mask, the warp below the unmasked u_t
+  if (int rc = forward(net, prec, src, kSrcWindow, B, H, W, F, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
                        as_stream(stream)))
     return rc;
   // model.py:120: stn(u_t, V_src, F_t, [h, w]) with V_src tiled over the batch (:111); float32
@@ -505,7 +509,7 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
 // frame table[b][6]; conv1 assembles the window in its load stage (eval.py:103-104) and, for a uint8 pool, applies the
 // / 255. of eval.py:80 there; the warp reads u_t from the pool through the same table.
 int stabilize_ring(const dvsg_locnet *net, int prec, const void *pool, int pool_is_u8, int n_pool, const int32_t *table,
-                   int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
+                   const float *mask, int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
                    size_t workspace_bytes, void *stream) {
   DVSG_REQUIRE(net && pool && table && s_t_pred && workspace, "dvsg_stabilize_ring: NULL pointer");
   DVSG_REQUIRE(B > 0 && B <= 65535 && n_pool > 0, "dvsg_stabilize_ring: B=%d n_pool=%d out of range", B, n_pool);
@@ -515,7 +519,8 @@ int stabilize_ring(const dvsg_locnet *net, int prec, const void *pool, int pool_
   if (ws.total > workspace_bytes)
     return fail(DVSG_ERR_WORKSPACE, "dvsg_stabilize_ring: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
   float *F = F_t ? F_t : ws.Ft;
-  const Conv1Src src{pool, table, n_pool};
+  Conv1Src src{pool, table, n_pool};
+  src.mask = mask;
   if (int rc = forward(net, prec, src, pool_is_u8 ? kSrcRingU8 : kSrcRingF32, B, H, W, F, -1, nullptr, 0, nullptr, workspace,
                        workspace_bytes, as_stream(stream)))
     return rc;
@@ -832,19 +837,19 @@ int dvsg_debug_set_option(const char *name, int value) {
 int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                        void *stream) {
-  return stabilize(net, kF32, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+  return stabilize(net, kF32, patches_t, u_t, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
 }
 
 int dvsg_stabilize_f32s(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
                         float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                         void *stream) {
-  return stabilize(net, kF32S, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+  return stabilize(net, kF32S, patches_t, u_t, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
 }
 
 int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
                        float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
                        void *stream) {
-  return stabilize(net, kF16, patches_t, u_t, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+  return stabilize(net, kF16, patches_t, u_t, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
 }
 
 static int ring_precision(int precision) {
@@ -854,15 +859,59 @@ static int ring_precision(int precision) {
 int dvsg_stabilize_ring_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool, const int32_t *table,
                             int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
                             size_t workspace_bytes, void *stream) {
-  return stabilize_ring(net, ring_precision(precision), pool, 0, n_pool, table, B, H, W, s_t_pred, F_t, x_s, y_s, workspace,
-                        workspace_bytes, stream);
+  return stabilize_ring(net, ring_precision(precision), pool, 0, n_pool, table, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s,
+                        workspace, workspace_bytes, stream);
 }
 
 int dvsg_stabilize_ring_u8(const dvsg_locnet_t *net, int precision, const uint8_t *pool, int n_pool, const int32_t *table,
                            int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace,
                            size_t workspace_bytes, void *stream) {
-  return stabilize_ring(net, ring_precision(precision), pool, 1, n_pool, table, B, H, W, s_t_pred, F_t, x_s, y_s, workspace,
-                        workspace_bytes, stream);
+  return stabilize_ring(net, ring_precision(precision), pool, 1, n_pool, table, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s,
+                        workspace, workspace_bytes, stream);
+}
+
+// eval_train.py's evaluation graph (:25-51): F_t = localizationNet(patches_t * mask), the warp on the unmasked u_t.
+int dvsg_stabilize_masked_f32(const dvsg_locnet_t *net, int precision, const float *patches_t, const float *u_t,
+                              const float *mask, int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(mask, "dvsg_stabilize_masked_f32: NULL mask");
+  return stabilize(net, ring_precision(precision), patches_t, u_t, mask, B, H, W, s_t_pred, F_t, x_s, y_s, workspace,
+                   workspace_bytes, stream);
+}
+
+int dvsg_stabilize_ring_masked_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool,
+                                   const int32_t *table, const float *mask, int B, int H, int W, float *s_t_pred, float *F_t,
+                                   float *x_s, float *y_s, void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(mask, "dvsg_stabilize_ring_masked_f32: NULL mask");
+  return stabilize_ring(net, ring_precision(precision), pool, 0, n_pool, table, mask, B, H, W, s_t_pred, F_t, x_s, y_s,
+                        workspace, workspace_bytes, stream);
+}
+
+int dvsg_stabilize_ring_masked_u8(const dvsg_locnet_t *net, int precision, const uint8_t *pool, int n_pool,
+                                  const int32_t *table, const float *mask, int B, int H, int W, float *s_t_pred, float *F_t,
+                                  float *x_s, float *y_s, void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(mask, "dvsg_stabilize_ring_masked_u8: NULL mask");
+  return stabilize_ring(net, ring_precision(precision), pool, 1, n_pool, table, mask, B, H, W, s_t_pred, F_t, x_s, y_s,
+                        workspace, workspace_bytes, stream);
+}
+
+// The CNN alone on a masked source -- F_t [B,25,2] into `out` (stage = -1) or the parity tap of `stage` (0..18).
+// src_kind 0: `src` is a window tensor [B,H,W,21] (n_pool, table unused); 1 / 2: a float32 / uint8 frame pool + table.
+int dvsg_locnet_forward_masked(const dvsg_locnet_t *net, int precision, const void *src_ptr, int src_kind, int n_pool,
+                               const int32_t *table, const float *mask, int B, int H, int W, int stage, float *out,
+                               size_t out_bytes, int *act_dims_host, void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(net && src_ptr && mask && out, "dvsg_locnet_forward_masked: NULL pointer");
+  DVSG_REQUIRE(src_kind >= 0 && src_kind <= 2 && (src_kind == 0 || (table && n_pool > 0)),
+               "dvsg_locnet_forward_masked: bad source (kind %d)", src_kind);
+  DVSG_REQUIRE(net->c_in == 21, "dvsg_locnet_forward_masked: the mask covers the 18 history channels of a 7-frame window");
+  DVSG_REQUIRE(stage >= -1 && stage <= 18 && (stage < 0 || act_dims_host), "dvsg_locnet_forward_masked: stage %d outside [-1,18]", stage);
+  DVSG_REQUIRE(stage >= 0 || out_bytes >= (size_t)B * 50 * sizeof(float), "dvsg_locnet_forward_masked: F_t needs B*50 floats");
+  const int prec = ring_precision(precision);
+  DVSG_REQUIRE(prec >= 0, "dvsg_locnet_forward_masked: unknown precision %d", precision);
+  Conv1Src src{src_ptr, src_kind ? table : nullptr, src_kind ? n_pool : 0};
+  src.mask = mask;
+  return forward(net, prec, src, src_kind, B, H, W, stage < 0 ? out : nullptr, stage, stage < 0 ? nullptr : out, out_bytes,
+                 act_dims_host, workspace, workspace_bytes, as_stream(stream));
 }
 
 int dvsg_locnet_forward_ring(const dvsg_locnet_t *net, int precision, const void *pool, int pool_is_u8, int n_pool,

@@ -286,9 +286,14 @@ struct TapsB<0> {  // generic channel count: the blend reads through the tap poi
 // of several pixels in flight before it blends the first one).  A tap on the ring reads as 0: the
 // loads are unconditional, from indices clamped into the image, and the ring is applied in the blend
 // as a select -- a predicated load that feeds arithmetic makes the compiler wait for each load in turn.
-template <int C>
-__device__ __forceinline__ void sample_padded_load(const float *__restrict__ img, int H, int W, int Cn, float x,
-                                                   float y, TapsB<C> &t) {
+// weights, ring flags and the (clamped) tap coordinates of one sample; shared by the image samplers and the mask plane
+struct PadGeom {
+  float w00, w01, w10, w11;
+  bool v00, v01, v10, v11;
+  int xa, xb, ya, yb;
+};
+__device__ __forceinline__ PadGeom padded_geom(int H, int W, float x, float y) {
+  PadGeom g;
   const float wf = (float)W, hf = (float)H;
   x = fminf(fmaxf(x, -1.0f), wf);  // (W-1)+1
   y = fminf(fmaxf(y, -1.0f), hf);
@@ -299,19 +304,28 @@ __device__ __forceinline__ void sample_padded_load(const float *__restrict__ img
   const int x0 = (int)x0f, y0 = (int)y0f;
   const int x1 = (int)fminf(x1f, wf + 1.0f);
   const int y1 = (int)fminf(y1f, hf + 1.0f);
-  t.w00 = (x1f - x) * (y1f - y);
-  t.w01 = (x - x0f) * (y1f - y);
-  t.w10 = (x1f - x) * (y - y0f);
-  t.w11 = (x - x0f) * (y - y0f);
+  g.w00 = (x1f - x) * (y1f - y);
+  g.w01 = (x - x0f) * (y1f - y);
+  g.w10 = (x1f - x) * (y - y0f);
+  g.w11 = (x - x0f) * (y - y0f);
   const bool vx0 = x0 >= 1 && x0 <= W, vx1 = x1 >= 1 && x1 <= W;
   const bool vy0 = y0 >= 1 && y0 <= H, vy1 = y1 >= 1 && y1 <= H;
-  t.v00 = vx0 && vy0; t.v01 = vx1 && vy0; t.v10 = vx0 && vy1; t.v11 = vx1 && vy1;
-  const int xa = clampi(x0 - 1, 0, W - 1), xb = clampi(x1 - 1, 0, W - 1);
-  const int ya = clampi(y0 - 1, 0, H - 1), yb = clampi(y1 - 1, 0, H - 1);
-  const float *p00 = img + ((long)ya * W + xa) * Cn;
-  const float *p01 = img + ((long)ya * W + xb) * Cn;
-  const float *p10 = img + ((long)yb * W + xa) * Cn;
-  const float *p11 = img + ((long)yb * W + xb) * Cn;
+  g.v00 = vx0 && vy0; g.v01 = vx1 && vy0; g.v10 = vx0 && vy1; g.v11 = vx1 && vy1;
+  g.xa = clampi(x0 - 1, 0, W - 1); g.xb = clampi(x1 - 1, 0, W - 1);
+  g.ya = clampi(y0 - 1, 0, H - 1); g.yb = clampi(y1 - 1, 0, H - 1);
+  return g;
+}
+
+template <int C>
+__device__ __forceinline__ void sample_padded_load(const float *__restrict__ img, int H, int W, int Cn, float x,
+                                                   float y, TapsB<C> &t) {
+  const PadGeom g = padded_geom(H, W, x, y);
+  t.w00 = g.w00; t.w01 = g.w01; t.w10 = g.w10; t.w11 = g.w11;
+  t.v00 = g.v00; t.v01 = g.v01; t.v10 = g.v10; t.v11 = g.v11;
+  const float *p00 = img + ((long)g.ya * W + g.xa) * Cn;
+  const float *p01 = img + ((long)g.ya * W + g.xb) * Cn;
+  const float *p10 = img + ((long)g.yb * W + g.xa) * Cn;
+  const float *p11 = img + ((long)g.yb * W + g.xb) * Cn;
   if constexpr (C > 0) {
     t.a = load_pix<C>(p00);
     t.b = load_pix<C>(p01);
@@ -611,6 +625,30 @@ __global__ __launch_bounds__(kThreads) void stn_kernel(StnParams p) {
   }
 }
 
+// eval_train.py:53-64 / model.py:156-167 `random_mask`: mask = ProjectiveTransformer(out_size).transform(ones, H).  The warp of an
+// all-ones image is the same in every channel, so ONE plane [B,H,W] is produced: the projective grid of stn_kernel<kProjective>
+// (:423-452) and sampler B's blend (:545-562) with every tap inside the image reading 1 and every tap on the zero ring 0 --
+// the same operations in the same order as the image path, no image.
+__global__ __launch_bounds__(kThreads) void mask_plane_kernel(const float *__restrict__ theta, int H, int W, float step_x,
+                                                             float step_y, float *__restrict__ out) {
+  const int b = blockIdx.z, i = blockIdx.y;
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  if (j >= W) return;
+  const float *th = theta + (size_t)b * 8;
+  const float x_t = -1.0f + step_x * (float)j;
+  const float y_t = -1.0f + step_y * (float)i;
+  const float xq = (th[0] * x_t + th[1] * y_t) + th[2];  // :438
+  const float yq = (th[3] * x_t + th[4] * y_t) + th[5];
+  const float zq = (th[6] * x_t + th[7] * y_t) + 1.0f;   // :430: the ninth entry is 1
+  const float xs = zq != 0.f ? xq / zq : 0.f;            // tf.div_no_nan (:446-447)
+  const float ys = zq != 0.f ? yq / zq : 0.f;
+  const float x = ((xs + 1.0f) / 2.0f) * ((float)W - 1.0f);  // :515-516
+  const float y = ((ys + 1.0f) / 2.0f) * ((float)H - 1.0f);
+  const PadGeom g = padded_geom(H, W, x, y);
+  out[((size_t)b * H + i) * W + j] =
+      ((g.w00 * (g.v00 ? 1.f : 0.f) + g.w01 * (g.v01 ? 1.f : 0.f)) + g.w10 * (g.v10 ? 1.f : 0.f)) + g.w11 * (g.v11 ? 1.f : 0.f);
+}
+
 __global__ __launch_bounds__(kThreads) void scale_rgb_kernel(const float *__restrict__ in,
                                                             float *__restrict__ out, size_t npix,
                                                             int C) {
@@ -831,6 +869,17 @@ int dvsg_grid_projective_f32(const float *theta, const float *im, int B, int H, 
   if (int rc = grid_common("dvsg_grid_projective_f32", p, im, B, H, W, C, out_h, out_w, out, x_s, y_s)) return rc;
   p.a = theta;
   return launch_stn<kProjective>(p, B, as_stream(stream), "stn_projective_kernel");
+}
+
+int dvsg_random_mask_plane_f32(const float *theta, int B, int H, int W, float *mask, void *stream) {
+  DVSG_REQUIRE(theta && mask, "dvsg_random_mask_plane_f32: NULL pointer");
+  if (int rc = check_image_args("dvsg_random_mask_plane_f32", B, H, W, 1, H, W)) return rc;
+  DVSG_REQUIRE(H <= 65535, "dvsg_random_mask_plane_f32: H=%d exceeds the grid limit 65535", H);
+  hipStream_t s = as_stream(stream);
+  ProfScope prof(kClsStn, s, 0.0, 4.0 * B * H * W);
+  hipLaunchKernelGGL(mask_plane_kernel, dim3(ceil_div(W, kThreads), H, B), dim3(kThreads), 0, s, theta, H, W, lin_step(W),
+                     lin_step(H), mask);
+  return check_launch("mask_plane_kernel");
 }
 
 int dvsg_grid_elastic_f32(const float *theta_abs, const float *L_inv, const float *source_points,

@@ -78,8 +78,9 @@ class LocNet(object):
             ws = self._ws[slot] = torch.empty(need.value, dtype=torch.uint8, device=device())
         return ws, need.value
 
-    def stabilize(self, patches, u_t, out, F, xs=None, ys=None, n_streams=1, precision="f32"):
-        """`dvsg_stabilize_f32` on device tensors, optionally with the batch split over
+    def stabilize(self, patches, u_t, out, F, xs=None, ys=None, n_streams=1, precision="f32", mask=None):
+        """`dvsg_stabilize_f32` on device tensors (with `mask` [B,H,W]: `dvsg_stabilize_masked_f32`, eval_train.py's
+        graph -- the plane multiplies the 18 history channels inside conv1's load stage), optionally with the batch split over
         `n_streams` side streams: every conv launch covers the chip in a few rounds of tiles and
         its last round is only partly full; launches from two independent half batches fill each
         other's tails (+4 % at B=16 720p before the stream-K tail, <1 % since).  Results do not
@@ -105,6 +106,12 @@ class LocNet(object):
                 raise ValueError("%s must be a contiguous float32 device tensor" % name)
             if n is not None and t.numel() != n:
                 raise ValueError("%s must hold B*H*W = %d values" % (name, n))
+        if mask is not None:
+            self._check_mask(mask, B, H, W)
+            ws, nbytes = self.workspace(B, H, W)
+            _lib.call("dvsg_stabilize_masked_f32", self.handle, self._PRECISION_CODE[precision], ptr(patches), ptr(u_t),
+                      ptr(mask), B, H, W, ptr(out), ptr(F), ptr(xs), ptr(ys), ptr(ws), nbytes, stream())
+            return
         if n_streams <= 1 or B < 2 * n_streams:
             ws, nbytes = self.workspace(B, H, W)
             _lib.call(fn, self.handle, ptr(patches), ptr(u_t), B, H, W, ptr(out), ptr(F),
@@ -144,10 +151,24 @@ class LocNet(object):
             raise ValueError("table must be a contiguous [B,7] int32 device tensor (clip.window_index_table)")
         return int(table.shape[0]), int(pool.shape[1]), int(pool.shape[2])
 
-    def stabilize_ring(self, pool, table, out, F, xs=None, ys=None, precision="f32"):
+    @staticmethod
+    def _check_mask(mask, B, H, W):
+        import torch
+        if not isinstance(mask, torch.Tensor) or mask.dtype != torch.float32 or not mask.is_cuda or not mask.is_contiguous() \
+                or tuple(mask.shape) != (B, H, W):
+            raise ValueError("mask must be a contiguous float32 device tensor [%d,%d,%d] (random_mask_plane)" % (B, H, W))
+
+    def random_mask_plane(self, H_theta, h, w):
+        """`dvsg_random_mask_plane_f32`: model.py:156-167 / eval_train.py:53-64's mask for homographies H_theta [B,8]
+        (the value after the scale and identity offset of :162-163) as ONE plane [B,h,w] -- the projective warp of an
+        all-ones image is the same in each of the 18 history channels."""
+        return random_mask_plane(H_theta, h, w)
+
+    def stabilize_ring(self, pool, table, out, F, xs=None, ys=None, precision="f32", mask=None):
         """`dvsg_stabilize_ring_f32` / `_u8`: the evaluation graph on windows assembled inside conv1's load stage
         from the frame pool [n,H,W,3] (float32 in [0,1], or raw uint8) through the index table [B,7]
-        (eval.py:103-104 and, for uint8, the / 255. of :80, fused); u_t of window b is pool frame table[b,6]."""
+        (eval.py:103-104 and, for uint8, the / 255. of :80, fused); u_t of window b is pool frame table[b,6].
+        With `mask` [B,H,W] (`random_mask_plane`): `dvsg_stabilize_ring_masked_*`, eval_train.py's graph."""
         import torch
         B, H, W = self._check_ring(pool, table)
         if precision not in self._PRECISION_CODE:
@@ -162,9 +183,47 @@ class LocNet(object):
             if n is not None and t.numel() != n:
                 raise ValueError("%s must hold B*H*W = %d values" % (name, n))
         ws, nbytes = self.workspace(B, H, W)
+        if mask is not None:
+            self._check_mask(mask, B, H, W)
+            fn = "dvsg_stabilize_ring_masked_u8" if pool.dtype == torch.uint8 else "dvsg_stabilize_ring_masked_f32"
+            _lib.call(fn, self.handle, self._PRECISION_CODE[precision], ptr(pool), int(pool.shape[0]), ptr(table), ptr(mask),
+                      B, H, W, ptr(out), ptr(F), ptr(xs), ptr(ys), ptr(ws), nbytes, stream())
+            return
         fn = "dvsg_stabilize_ring_u8" if pool.dtype == torch.uint8 else "dvsg_stabilize_ring_f32"
         _lib.call(fn, self.handle, self._PRECISION_CODE[precision], ptr(pool), int(pool.shape[0]), ptr(table), B, H, W,
                   ptr(out), ptr(F), ptr(xs), ptr(ys), ptr(ws), nbytes, stream())
+
+    def forward_masked(self, src, mask, table=None, precision="f32", stage=-1):
+        """`dvsg_locnet_forward_masked`: F_t [B,25,2] (stage -1) or the parity tap of `stage` (0 conv1, 1 pool1) with
+        the mask plane [B,H,W] multiplied into the history channels in conv1's load stage.  `src` is a window tensor
+        [B,H,W,21] (table None) or a frame pool [n,H,W,3] float32 / uint8 with its index table [B,7]."""
+        import torch
+        if table is None:
+            t = as_dev(src)
+            B, H, W, C = t.shape
+            if C != self.in_channels or C != 21:
+                raise ValueError("a masked window has 21 channels, got %d (conv1: %d)" % (C, self.in_channels))
+            kind, n_pool = 0, 0
+        else:
+            t = src
+            B, H, W = self._check_ring(t, table)
+            kind, n_pool = (2 if t.dtype == torch.uint8 else 1), int(t.shape[0])
+        self._check_mask(mask, B, H, W)
+        if stage > 1:
+            raise ValueError("forward_masked taps stages 0 (conv1) and 1 (pool1); later stages do not depend on the source")
+        ws, nbytes = self.workspace(B, H, W)
+        dims = (ctypes.c_int * 3)()
+        if stage < 0:
+            buf = torch.empty((B, 25, 2), dtype=torch.float32, device=t.device)
+        else:
+            h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            buf = torch.empty((B * max(h1 * w1 * 64, 2048),), dtype=torch.float32, device=t.device)
+        _lib.call("dvsg_locnet_forward_masked", self.handle, self._PRECISION_CODE[precision], ptr(t), kind, n_pool,
+                  ptr(table), ptr(mask), B, H, W, int(stage), ptr(buf), buf.numel() * 4, dims, ptr(ws), nbytes, stream())
+        if stage < 0:
+            return buf
+        h, w, c = dims[0], dims[1], dims[2]
+        return buf[:B * h * w * c].reshape(B, h, w, c)
 
     def forward_ring(self, pool, table, precision="f32", stage=-1):
         """`dvsg_locnet_forward_ring`: F_t [B,25,2] (stage -1) or the parity tap of `stage` from a frame ring."""
@@ -220,6 +279,18 @@ class LocNet(object):
                   dims, ptr(ws), nbytes, stream())
         h, w, c = dims[0], dims[1], dims[2]
         return buf[:B * h * w * c].reshape(B, h, w, c)
+
+
+def random_mask_plane(H_theta, h, w):
+    """model.py:156-167 / eval_train.py:53-64: ProjectiveTransformer([h, w]).transform(ones, H_theta)[..., 0] for
+    H_theta [B,8] (after the scale and identity offset of :162-163), float32 [B,h,w] on the device."""
+    tt = as_dev(H_theta)
+    if tt.dim() != 2 or tt.shape[1] != 8:
+        raise ValueError("H must be [B,8], got %s" % (tuple(tt.shape),))
+    B = int(tt.shape[0])
+    out = empty((B, int(h), int(w)), tt)
+    _lib.call("dvsg_random_mask_plane_f32", ptr(tt), B, int(h), int(w), ptr(out), stream())
+    return out
 
 
 def load_localizationNet(weights, scope="stabNet/localizationNet"):

@@ -307,6 +307,36 @@ int dvsg_stabilize_ring_u8(const dvsg_locnet_t *net, int precision, const uint8_
 int dvsg_locnet_forward_ring(const dvsg_locnet_t *net, int precision, const void *pool, int pool_is_u8, int n_pool,
                              const int32_t *table, int B, int H, int W, int stage, float *out, size_t out_bytes,
                              int *act_dims_host, void *workspace, size_t workspace_bytes, void *stream);
+/* ---------------------------------------------------------------------------------------
+ * eval_train.py's evaluation graph (eval_train.py:25-51): unlike model.py's, its CNN input is
+ * `patches_masked_t = patches_t * mask` (:43-45), where `random_mask` (:53-64, = model.py:156-167) warps an all-ones
+ * image of the 18 history channels with ProjectiveTransformer and a near-identity homography H and leaves the newest
+ * frame's 3 channels unmasked; the TPS warp still samples the UNMASKED u_t (:48).
+ *   dvsg_random_mask_plane_f32  theta [B,8] (the homography of :55-57 AFTER its scale and identity offset; the
+ *          reference draws it with tf.random_uniform inside the graph, here the caller supplies it) -> mask [B,H,W]:
+ *          ProjectiveTransformer(out_size).transform(ones, theta) -- grid (spatial_transformer.py:423-452) and
+ *          sampler B's blend (:545-562) on taps that read 1 inside the image and 0 on the zero ring.  The warp of an
+ *          all-ones image is the same in every channel, so ONE plane stands for `random_masks_t[..., :18]`.
+ *   dvsg_stabilize_masked_f32 / dvsg_stabilize_ring_masked_{f32,u8}: dvsg_stabilize_* / dvsg_stabilize_ring_* with that
+ *          plane multiplied into the 18 history channels INSIDE conv1's load stage ((x * m) * 255 - mean, three
+ *          roundings like the TF ops); neither a [B,H,W,21] product tensor nor a multiply launch exists.  A plane of
+ *          exact ones reproduces the unmasked entry points bit for bit.  precision: DVSG_PRECISION_*.
+ *   dvsg_locnet_forward_masked: the CNN alone (stage -1: F_t into `out`) or a parity tap (stage 0..18) from a masked
+ *          source; src_kind 0 = window tensor [B,H,W,21], 1 = float32 frame pool + table, 2 = uint8 frame pool + table.
+ * ------------------------------------------------------------------------------------- */
+int dvsg_random_mask_plane_f32(const float *theta, int B, int H, int W, float *mask, void *stream);
+int dvsg_stabilize_masked_f32(const dvsg_locnet_t *net, int precision, const float *patches_t, const float *u_t,
+                              const float *mask, int B, int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_stabilize_ring_masked_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool,
+                                   const int32_t *table, const float *mask, int B, int H, int W, float *s_t_pred, float *F_t,
+                                   float *x_s, float *y_s, void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_stabilize_ring_masked_u8(const dvsg_locnet_t *net, int precision, const uint8_t *pool, int n_pool,
+                                  const int32_t *table, const float *mask, int B, int H, int W, float *s_t_pred, float *F_t,
+                                  float *x_s, float *y_s, void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_locnet_forward_masked(const dvsg_locnet_t *net, int precision, const void *src, int src_kind, int n_pool,
+                               const int32_t *table, const float *mask, int B, int H, int W, int stage, float *out,
+                               size_t out_bytes, int *act_dims_host, void *workspace, size_t workspace_bytes, void *stream);
 /* eval.py:112 `np.uint8(x * 255.)`: float64 product, truncation toward zero (values outside
  * [0, 256) saturate; NumPy leaves them undefined).  src [n,H,W,3] float32 is written into columns
  * [dst_x0, dst_x0 + W) of dst [n,H,dst_W,3] uint8 -- dst_W = 2 W and dst_x0 = 0 / W give the

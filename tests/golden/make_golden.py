@@ -34,6 +34,9 @@ CASES = {
     "clip": dict(N=40, H=32, W=48),
     # BASELINE.json configs[0]: one 256x256 window through the evaluation graph (eval.py path)
     "cfg0_256": dict(B=1, H=256, W=256),
+    # eval_train.py:25-51,137-165: the teacher-forced loop through eval_train.py's OWN graph (masked CNN input), the
+    # homography of every step drawn from a seed (inputs.mask_homographies) instead of tf.random_uniform
+    "eval_train": dict(N=38, H=32, W=48),
 }
 
 
@@ -97,13 +100,28 @@ def cfg0_case(weights):
                 xs_sub=xs[::16].astype(np.float32), ys_sub=ys[::16].astype(np.float32))
 
 
+def eval_train_case(weights):
+    c = CASES["eval_train"]
+    N, H, W = c["N"], c["H"], c["W"]
+    stab, unstab = inputs.stable_unstable_clips(6001, N, H, W)
+    mask_H = inputs.mask_homographies(6002, N - 32)
+    grids, f_t = [], []
+    outs = omodel.eval_train_clip(weights, unstab, stab, H, W, mask_H, grids=grids, f_t=f_t)
+    mask = np.stack([otps.border_discontinuity_mask(xs, ys, H, W, delta=3e-2) for xs, ys in grids])
+    # what the round-3 loop computed instead (model.py's graph on the same windows): must DIFFER from the masked result
+    plain = omodel.eval_train_clip(weights, unstab, stab, H, W, np.tile(omodel.RANDOM_MASK_OFFSET, (N - 32, 1)))
+    return dict(stabilised=outs, F_t=np.stack(f_t), border_mask_bits=np.packbits(mask), mask_H=mask_H,
+                stabilised_identity_mask=plain)
+
+
 def main():
     weights = make_synthetic_weights(seed=0)
+    np.savez_compressed(os.path.join(HERE, "eval_train.npz"), **eval_train_case(weights))
     np.savez_compressed(os.path.join(HERE, "warps.npz"), **warps_case())
     np.savez_compressed(os.path.join(HERE, "locnet.npz"), **locnet_case(weights))
     np.savez_compressed(os.path.join(HERE, "clip.npz"), **clip_case(weights))
     np.savez_compressed(os.path.join(HERE, "cfg0_256.npz"), **cfg0_case(weights))
-    for f in ("warps.npz", "locnet.npz", "clip.npz", "cfg0_256.npz"):
+    for f in ("warps.npz", "locnet.npz", "clip.npz", "cfg0_256.npz", "eval_train.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -52,3 +52,18 @@ def v_src(B):
     lin = np.linspace(-1.0, 1.0, 5)
     pts = np.array([[x, y] for y in lin for x in lin], dtype=np.float32)
     return np.tile(pts[None], (B, 1, 1))
+
+
+def mask_homographies(seed, n):
+    """[n,8] homographies of eval_train.py:55-57 / model.py:161-163: uniform[-1,1) * scale + identity, float32."""
+    u = np.random.default_rng(seed).uniform(-1.0, 1.0, (n, 8)).astype(np.float32)
+    scale = np.array([0.1, 0.1, 0.5, 0.1, 0.1, 0.5, 0.1, 0.1], dtype=np.float32)
+    ident = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], dtype=np.float32)
+    return ((u * scale).astype(np.float32) + ident).astype(np.float32)
+
+
+def stable_unstable_clips(seed, N, H, W):
+    """A (stable, unstable) pair of clips [N,H,W,3] for eval_train.py's teacher-forced loop."""
+    stab = smooth_frames(seed, N, H, W)
+    unstab = (np.roll(stab, 2, axis=2) * 0.9 + 0.05).astype(np.float32)
+    return stab, unstab

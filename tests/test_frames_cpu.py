@@ -80,3 +80,29 @@ def test_uint8_frames_survive_the_division_and_the_scale_exactly():
     x = (v / 255.).astype(np.float32)
     assert np.array_equal(x * np.float32(255.0), v.astype(np.float32))
     assert np.array_equal(v.astype(np.float32) / np.float32(255.0), x)
+
+
+def test_float32_quotient_of_a_byte_by_two_fused_multiply_adds():
+    """conv1's masked uint8 staging needs x = float32(v / 255.) itself (eval_train.py:119 `frame / 255.` in float64,
+    rounded once by the feed; the mask multiplies x before scale_RGB).  The kernel computes q = v * r,
+    x = fma(fma(-q, 255, v), r, q) with r = float32(1 / 255): exact arithmetic on fractions shows it is that value
+    for all 256 bytes (a plain v * r is not, for 126 of them)."""
+    from fractions import Fraction
+
+    def rn32(fr):   # a Fraction rounded to the nearest float32, ties to even
+        f = np.float32(float(fr))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return min(cands, key=lambda c: (abs(Fraction(float(c)) - fr), int(np.float32(c).view(np.uint32)) & 1))
+
+    r = np.float32(1.0) / np.float32(255.0)
+    plain_bad = 0
+    for v in range(256):
+        want = np.float32(np.float64(v) / np.float64(255.0))
+        q = np.float32(v) * r
+        rem = rn32(Fraction(float(v)) - Fraction(float(q)) * 255)
+        assert Fraction(float(rem)) == Fraction(float(v)) - Fraction(float(q)) * 255      # the inner fma is exact
+        got = rn32(Fraction(float(rem)) * Fraction(float(r)) + Fraction(float(q)))
+        assert got == want, v
+        assert np.float32(want * np.float32(1.0)) * np.float32(255.0) == np.float32(v)    # mask 1.0: the unmasked staging's float(v)
+        plain_bad += q != want
+    assert plain_bad > 0

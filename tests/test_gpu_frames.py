@@ -119,24 +119,27 @@ def test_uint8_clip_in_uint8_clip_out(synthetic_weights):
         stabilize_clip(model, None, frames[:, :-1])
 
 
-def test_teacher_forced_clip_matches_eval_train(synthetic_weights):
-    """eval_train.py:137-165: independent windows (history from the stable clip), run batched."""
+def test_teacher_forced_clip_without_a_mask_is_model_py_on_the_same_windows(synthetic_weights):
+    """`mask_H=None`: model.py's graph (model.py:98-123) on eval_train.py's teacher-forced windows (:137-165) -- NOT
+    eval_train.py's own graph, whose CNN input is masked (tests/test_gpu_masked.py covers that one).  The oracle runs
+    the masked graph with an identity homography per step, whose mask is exactly one."""
     from coupe.dvsg_amd.clip import stabilize_clip_teacher_forced
     from coupe.dvsg_amd.model import StabNet
     H, W, N = 32, 48, 37
     stab = inputs.smooth_frames(6001, N, H, W)
     unstab = np.roll(stab, 2, axis=2) * 0.9 + 0.05
     model = StabNet(H, W).load_weights(synthetic_weights)
-    ref = omodel.eval_train_clip(synthetic_weights, unstab, stab, H, W)
+    ident = np.tile(omodel.RANDOM_MASK_OFFSET, (N - 32, 1))
+    ref = omodel.eval_train_clip(synthetic_weights, unstab, stab, H, W, ident)
     for batch in (2, 16):
-        out = stabilize_clip_teacher_forced(model, unstab, stab, batch=batch)
+        out = stabilize_clip_teacher_forced(model, unstab, stab, batch=batch, mask_H=None)
         assert out.shape == (N - 32, H, W, 3) and out.dtype == np.float32
         assert np.abs(out - ref).max() < 2e-2 and np.median(np.abs(out - ref)) < 1e-5
     u8 = stabilize_clip_teacher_forced(model, (unstab * 255).astype(np.uint8), (stab * 255).astype(np.uint8), batch=3,
-                                       as_uint8=True)
+                                       as_uint8=True, mask_H=None)
     assert u8.dtype == np.uint8 and u8.shape == (N - 32, H, W, 3)
     ref8 = omodel.eval_train_clip(synthetic_weights, (unstab * 255).astype(np.uint8) / 255.,
-                                  (stab * 255).astype(np.uint8) / 255., H, W)
+                                  (stab * 255).astype(np.uint8) / 255., H, W, ident)
     diff = np.abs(u8.astype(int) - oframes.to_uint8(ref8).astype(int))
     assert (diff > 1).mean() < 0.01 and np.median(diff) == 0
 
@@ -157,7 +160,7 @@ def _tf_worker(rank, world, port, out_dir):
         stab = inputs.smooth_frames(6001, N, H, W)
         unstab = np.roll(stab, 2, axis=2) * 0.9 + 0.05
         model = StabNet(H, W).load_weights(make_synthetic_weights(seed=0))
-        out = stabilize_clip_teacher_forced(model, unstab, stab, batch=2)
+        out = stabilize_clip_teacher_forced(model, unstab, stab, batch=2, mask_H=inputs.mask_homographies(6003, N - 32))
         if rank == 0:
             np.save(os.path.join(out_dir, "out.npy"), out)
         else:
@@ -168,7 +171,8 @@ def _tf_worker(rank, world, port, out_dir):
 
 def test_teacher_forced_clip_sharded_over_two_ranks(tmp_path, synthetic_weights):
     """The N > 1 path with the real kernels: two processes shard the 7 windows 4 + 3, no data-path
-    collective, one gather -- same frames as a single process."""
+    collective, one gather -- same frames as a single process; eval_train.py's masked graph, each rank making the
+    mask planes of its own windows from the shared table of homographies."""
     import socket
     import torch.multiprocessing as mp
     from coupe.dvsg_amd.clip import stabilize_clip_teacher_forced
@@ -181,7 +185,10 @@ def test_teacher_forced_clip_sharded_over_two_ranks(tmp_path, synthetic_weights)
     H, W, N = 32, 48, 39
     stab = inputs.smooth_frames(6001, N, H, W)
     unstab = np.roll(stab, 2, axis=2) * 0.9 + 0.05
-    single = stabilize_clip_teacher_forced(StabNet(H, W).load_weights(synthetic_weights), unstab, stab, batch=2)
+    single = stabilize_clip_teacher_forced(StabNet(H, W).load_weights(synthetic_weights), unstab, stab, batch=2,
+                                           mask_H=inputs.mask_homographies(6003, N - 32))
+    plain = stabilize_clip_teacher_forced(StabNet(H, W).load_weights(synthetic_weights), unstab, stab, batch=2, mask_H=None)
+    assert np.abs(single - plain).max() > 1e-3                      # the mask is really in the sharded path
     got = np.load(tmp_path / "out.npy")
     assert got.shape == single.shape == (N - 32, H, W, 3)
     assert np.abs(got - single).max() <= 1e-6

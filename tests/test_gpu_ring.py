@@ -235,10 +235,18 @@ def test_init_vars_feeds_the_gpu_model(tmp_path, synthetic_weights):
     path = str(tmp_path / "resnet_v1_50.ckpt")
     tfc.write_bundle(path, ckpt)
     H, W = 40, 64
-    model = StabNet(H, W).init_vars(synthetic_weights, ckpt_path=path)
+    model = StabNet(H, W).load_weights(synthetic_weights)      # the variables exist (tf.global_variables_initializer)
+    sess = Session()
+    assert model.init_vars(sess, ckpt_path=path) is model      # model.py:125: init_vars(sess)
     ins, outs = model.get_evaluation_model(7)
     x = inputs.window_frames(291, 1, H, W)
     F = Session().run(outs["F_t"], {ins["patches_t"]: x, ins["u_t"]: x[..., 18:]})
     merged = tfc.init_from_slim_checkpoint(synthetic_weights, path)
     assert np.abs(F - onet.localizationNet(x, 25, merged)).max() <= 1e-5
     assert np.abs(F - onet.localizationNet(x, 25, synthetic_weights)).max() > 1e-4      # it really is another network
+    F3 = Session().run(outs["F_t"], {ins["patches_t"]: x, ins["u_t"]: x[..., 18:]})
+    model3 = StabNet(H, W).init_vars(synthetic_weights, ckpt_path=path)                 # round 3's call form still works
+    ins3, outs3 = model3.get_evaluation_model(7)
+    assert np.array_equal(F3, Session().run(outs3["F_t"], {ins3["patches_t"]: x, ins3["u_t"]: x[..., 18:]}))
+    with pytest.raises(Exception):
+        StabNet(H, W).init_vars(sess, ckpt_path=path)                                   # nothing to initialise

@@ -78,3 +78,40 @@ def test_cfg0_golden(synthetic_weights):
     mask = np.unpackbits(g["border_mask_bits"])[:H * W].astype(bool).reshape(1, H, W)
     assert 0 < mask.sum() < 0.02 * H * W
     assert np.abs(pred - g["s_t_pred"]).max(axis=3)[~mask].max() < 1e-3
+
+
+def test_eval_train_golden(synthetic_weights):
+    """eval_train.py:25-51,137-165: the teacher-forced loop through eval_train.py's own graph -- the CNN sees the
+    window times the random projective mask (:43-45), the warp the unmasked frame (:48)."""
+    g = _load("eval_train.npz")
+    N, H, W = 38, 32, 48
+    stab, unstab = inputs.stable_unstable_clips(6001, N, H, W)
+    assert np.array_equal(g["mask_H"], inputs.mask_homographies(6002, N - 32))
+    f_t = []
+    outs = omodel.eval_train_clip(synthetic_weights, unstab, stab, H, W, g["mask_H"], f_t=f_t)
+    assert outs.shape == g["stabilised"].shape == (N - 32, H, W, 3)
+    assert np.abs(np.stack(f_t) - g["F_t"]).max() < 5e-6
+    mask = np.unpackbits(g["border_mask_bits"])[:(N - 32) * H * W].astype(bool).reshape(N - 32, H, W)
+    assert np.abs(outs - g["stabilised"]).max(axis=3)[~mask].max() < 1e-3
+    # the mask matters: model.py's graph on the same windows (what an unmasked loop computes) gives other frames
+    assert np.abs(g["stabilised"] - g["stabilised_identity_mask"]).max() > 1e-2
+
+
+def test_eval_train_graph_is_the_masked_graph(synthetic_weights):
+    """EvalTrainNet (eval_train.py:25-51) = StabNet's graph (model.py:98-123) on patches * mask, warp on the unmasked u_t."""
+    B, H, W = 2, 32, 48
+    x = inputs.window_frames(6101, B, H, W)
+    Hm = inputs.mask_homographies(6102, B)
+    F, pm, m, pred = omodel.EvalTrainNet(H, W).run(synthetic_weights, x, x[..., 18:], Hm,
+                                                    fetch=("F_t", "patches_masked_t", "random_masks_t", "s_t_pred"))
+    assert np.array_equal(pm, x * m) and np.all(m[..., 18:] == 1.0) and (m[..., :18] < 1.0).any()
+    for c in range(1, 18):
+        assert np.array_equal(m[..., c], m[..., 0])          # ONE plane: what the GPU path multiplies in conv1's load stage
+    F2, pred2 = omodel.StabNet(H, W).run(synthetic_weights, pm, x[..., 18:], fetch=("F_t", "s_t_pred"))
+    assert np.array_equal(F, F2) and np.array_equal(pred, pred2)
+    F3 = omodel.StabNet(H, W).run(synthetic_weights, x, x[..., 18:], fetch=("F_t",))[0]
+    assert np.abs(F - F3).max() > 1e-5                       # and it is not the unmasked prediction
+    # identity homography: the mask is exactly one everywhere (sampler B on the unit grid), i.e. model.py's graph
+    ident = np.tile(omodel.RANDOM_MASK_OFFSET, (B, 1))
+    Fi, mi = omodel.EvalTrainNet(H, W).run(synthetic_weights, x, x[..., 18:], ident, fetch=("F_t", "random_masks_t"))
+    assert np.all(mi == 1.0) and np.array_equal(Fi, F3)
