@@ -14,18 +14,24 @@ BLOCKS = [("block1", 64, 3, 2), ("block2", 128, 4, 2), ("block3", 256, 6, 2), ("
 PREFIX = "stabNet/localizationNet/"
 
 
-def _w(weights, name):
+def _w(weights, name, dtype=torch.float32):
     for k in (name, name + ":0"):
         if k in weights:
-            return torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32))
+            return torch.from_numpy(np.ascontiguousarray(weights[k], dtype=np.float32)).to(dtype)
     raise KeyError(name)
 
 
 class TorchLocNet:
-    """Holds weights converted once (OIHW, BN as scale/shift applied AFTER the conv)."""
+    """Holds weights converted once (OIHW, BN as scale/shift applied AFTER the conv).  dtype=torch.float64: the same
+    graph on the same float32 weights and frames with every operation in float64 -- an ARBITER between two float32
+    evaluations (this one's and the GPU's), not the reference's arithmetic."""
 
-    def __init__(self, weights, prefix=PREFIX):
+    def __init__(self, weights, prefix=PREFIX, dtype=torch.float32):
         self.p = prefix
+        self.dtype = dtype
+
+        def _w(weights, name, _load=globals()["_w"]):   # the module-level loader, in this instance's dtype
+            return _load(weights, name, dtype)
         self.convs = {}
         rn = prefix + "resnet_v1_50"
         scopes = [rn + "/conv1"]
@@ -59,7 +65,7 @@ class TorchLocNet:
 
     @torch.no_grad()
     def features(self, patches_nhwc):
-        x = torch.as_tensor(patches_nhwc, dtype=torch.float32)
+        x = torch.as_tensor(patches_nhwc, dtype=torch.float32).to(self.dtype)
         # scale_RGB (networks.py:6-16): groups of 7 channels reversed, per-group mean
         x = x * 255.0
         g1, g2, g3 = torch.split(x, x.shape[3] // 3, dim=3)
@@ -94,4 +100,4 @@ class TorchLocNet:
             h = h @ W + b
             if i < 3:
                 h = F.leaky_relu(h, 0.2)
-        return h.reshape(-1, param_dim, 2).numpy()
+        return h.reshape(-1, param_dim, 2).numpy()   # (float64 for the arbiter)

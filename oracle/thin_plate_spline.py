@@ -138,3 +138,57 @@ def border_discontinuity_mask(xs, ys, H, W, delta=1e-2):
         for e in edges:
             m |= np.abs(v - e) < delta
     return m
+
+
+# ------------------------------------------------------------------------------------------------------------
+# A float64 ARBITER of the same map (not a restatement of reference arithmetic: the reference computes in float32).
+# Two correct float32 evaluations of the 28-term map differ by their rounding noise (SURVEY.md section 7 hard part
+# 2: ~3e-3 px at W = 3840), so "GPU against the float32 oracle" mixes the GPU's error with the oracle's own.  The
+# arbiter evaluates the map the reference DEFINES -- the same float32 inputs (control points, right-hand side, the
+# float32 grid values of tf.linspace, the float32 constant 1e-6), every operation in float64 -- and lets a test ask
+# the two float32 evaluations separately how far each is from it.
+# ------------------------------------------------------------------------------------------------------------
+def source_coords_f64(coord, rhs_points, out_h, out_w, rows=None):
+    """(x_s, y_s) of ThinPlateSpline.py:92-134,143-166 in float64, [B, n_rows*out_w]; `rows` (default all) selects
+    output rows, so a 3840x2160 grid can be checked a band at a time."""
+    coord64 = np.asarray(np.asarray(coord, dtype=F32), dtype=np.float64)
+    T = solve_system(coord64, np.asarray(np.asarray(rhs_points, dtype=F32), dtype=np.float64), dtype=np.float64)
+    xl, yl = meshgrid_xy(out_h, out_w)
+    xl = xl.astype(np.float64)
+    yl = yl.astype(np.float64)
+    if rows is not None:
+        yl = yl[np.asarray(rows)]
+    B, P, _ = coord64.shape
+    eps = np.float64(EPS)
+    xs = np.empty((B, yl.size * out_w), dtype=np.float64)
+    ys = np.empty_like(xs)
+    for b in range(B):
+        dx2 = np.square(xl[None, :] - coord64[b, :, 0:1])          # [P, W]
+        dy2 = np.square(yl[None, :] - coord64[b, :, 1:2])          # [P, rows]
+        d2 = dy2[:, :, None] + dx2[:, None, :]                      # [P, rows, W]
+        r = (d2 * np.log(d2 + eps)).reshape(P, -1)
+        x_t = np.tile(xl[None, :], (yl.size, 1)).reshape(-1)
+        y_t = np.tile(yl[:, None], (1, out_w)).reshape(-1)
+        for k, dst in ((0, xs), (1, ys)):
+            dst[b] = T[b, k, 0] + T[b, k, 1] * x_t + T[b, k, 2] * y_t + T[b, k, 3:] @ r
+    return xs, ys
+
+
+def interpolate_a_f64(im, x, y):
+    """Sampler A (ThinPlateSpline.py:30-90) evaluated in float64 at float64 coordinates x, y [B,N]: the frame the
+    reference's definition yields when the map is evaluated without float32 noise.  Returns [B,N,C] float64."""
+    im = np.asarray(im, dtype=np.float64)
+    B, H, W, C = im.shape
+    x = (np.asarray(x, dtype=np.float64) + 1.0) * W / 2.0
+    y = (np.asarray(y, dtype=np.float64) + 1.0) * H / 2.0
+    x0 = np.floor(x).astype(np.int64)
+    y0 = np.floor(y).astype(np.int64)
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = np.clip(x0, 0, W - 1), np.clip(x1, 0, W - 1)
+    y0, y1 = np.clip(y0, 0, H - 1), np.clip(y1, 0, H - 1)
+    bidx = np.arange(B)[:, None]
+    wa = ((x1 - x) * (y1 - y))[..., None]
+    wb = ((x1 - x) * (y - y0))[..., None]
+    wc = ((x - x0) * (y1 - y))[..., None]
+    wd = ((x - x0) * (y - y0))[..., None]
+    return wa * im[bidx, y0, x0] + wb * im[bidx, y1, x0] + wc * im[bidx, y0, x1] + wd * im[bidx, y1, x1]

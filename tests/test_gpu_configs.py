@@ -69,14 +69,18 @@ def test_cfg0_single_256_window(synthetic_weights):
     assert mask.mean() < 0.02
 
 
-def test_cfg1_stabilize_b16_720p_end_to_end(dev, synthetic_weights):
+@pytest.mark.parametrize("wseed,fseed", [(0, 77), (5, 1077)])
+def test_cfg1_stabilize_b16_720p_end_to_end(dev, wseed, fseed):
     """configs[1]: the benchmarked call itself -- ONE `dvsg_stabilize_f32` over B=16 720p windows --
     with two of the windows checked end to end against the CPU oracle: F_t <= 1e-5, source grid
-    < 2e-2 px, warped pixels < 1e-3 outside the counted sampler-A border-discontinuity pixels."""
+    < 2e-2 px, warped pixels < 1e-3 outside the counted sampler-A border-discontinuity pixels.  Two seeds of
+    checkpoint and frames (round 4: every 720p end-to-end figure used to ride on seed 0)."""
     import torch
     from coupe.dvsg_amd.networks import LocNet
+    from coupe.dvsg_amd.weights import make_synthetic_weights
+    synthetic_weights = make_synthetic_weights(seed=wseed)
     B, H, W = 16, H720, W720
-    x = _gpu_windows(B, H, W, 77, dev)
+    x = _gpu_windows(B, H, W, fseed, dev)
     u = x[..., 18:].contiguous()
     net = LocNet(synthetic_weights)
     out = torch.empty((B, H, W, 3), device=dev)
@@ -94,6 +98,8 @@ def test_cfg1_stabilize_b16_720p_end_to_end(dev, synthetic_weights):
         assert gerr < 2e-2, "window %d: grid error %.3g px" % (b, gerr)
         mask = otps.border_discontinuity_mask(rxs, rys, H, W, delta=3e-2).reshape(H, W)
         err = np.abs(out[b].cpu().numpy() - rpred[0]).max(axis=2)
+        print("cfg1 seeds (%d, %d) window %d: F_t %.3g, grid %.3g px, pixels %.3g outside %d border pixels"
+              % (wseed, fseed, b, np.abs(F[b:b + 1].cpu().numpy() - rF).max(), gerr, err[~mask].max(), int(mask.sum())))
         assert err[~mask].max() < 1e-3, "window %d: pixel error %.3g" % (b, err[~mask].max())
         assert mask.mean() < 0.01
 
@@ -178,12 +184,30 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
     # (tests/test_gpu_fullsize.py::test_tps_warp_4k_against_oracle) times the frames' gradient (<= 0.2 per pixel)
     rpred, rxs, rys = otps.ThinPlateSpline(u[21:22].cpu().numpy(), inputs.v_src(1), rF, (H, W))
     mask = otps.border_discontinuity_mask(rxs, rys, H, W, delta=5e-2).reshape(H, W)
-    perr = np.abs(out[21].cpu().numpy() - rpred[0]).max(axis=2)
-    print("cfg4 window 21: F_t error %.3g, pixels max %.3g median %.3g outside %d border pixels"
-          % (err, perr[~mask].max(), np.median(perr), int(mask.sum())))
-    # measured (round 3): F_t 9.7e-7, pixels 9.6e-4 max / 8.8e-5 median outside 476 border pixels -- at the 1e-3 target,
-    # not inside it with margin: 1.9e-3 px of F_t error + 3e-3 px of float32 map evaluation, times a gradient of 0.2
-    assert perr[~mask].max() < 1.5e-3, "window 21: pixel error %.3g" % perr[~mask].max()
+    got21 = out[21].cpu().numpy()
+    perr = np.abs(got21 - rpred[0]).max(axis=2)
+    # ... and against the float64 ARBITER of the same definition (oracle/thin_plate_spline.py `source_coords_f64` +
+    # `interpolate_a_f64`: the oracle's F_t, the map and sampler A evaluated in float64).  At W = 3840 the float32 oracle
+    # is itself ~3e-3 px x gradient away from that frame (tests/test_gpu_fullsize.py::..._float64_arbiter), so the
+    # distance between two float32 evaluations is not the GPU's error: the bound of record is the one against the arbiter.
+    rhs = (inputs.v_src(1) + rF).astype(np.float32)
+    u21 = u[21:22].cpu().numpy()
+    e64 = np.zeros((H, W))
+    o64 = np.zeros((H, W))
+    for r0 in range(0, H, 240):
+        rows = np.arange(r0, min(H, r0 + 240))
+        xb, yb = otps.source_coords_f64(inputs.v_src(1), rhs, H, W, rows=rows)
+        f64 = otps.interpolate_a_f64(u21, xb, yb)[0].reshape(len(rows), W, 3)
+        e64[rows] = np.abs(got21[rows] - f64).max(axis=2)
+        o64[rows] = np.abs(rpred[0][rows] - f64).max(axis=2)
+    print("cfg4 window 21: F_t error %.3g; pixels vs float32 oracle max %.3g median %.3g; vs float64 arbiter: GPU %.3g, "
+          "float32 oracle %.3g (outside %d border pixels)"
+          % (err, perr[~mask].max(), np.median(perr), e64[~mask].max(), o64[~mask].max(), int(mask.sum())))
+    # measured: F_t 9.6e-7; pixels 9.0e-4 max / 9.0e-5 median against the float32 oracle (round 3: 9.6e-4) -- but 3.9e-4
+    # against the float64 arbiter, from which the float32 ORACLE is 9.0e-4 away: the zero margin of round 3 was the
+    # oracle's own float32 noise at W = 3840, not the float16 mode's error (476 border pixels)
+    assert e64[~mask].max() < 1e-3, "window 21: pixel error %.3g against the float64 arbiter" % e64[~mask].max()
+    assert perr[~mask].max() < 1e-3 + o64[~mask].max(), "window 21: pixel error %.3g against the float32 oracle" % perr[~mask].max()
     assert mask.mean() < 0.005
     del out, o1, rpred, perr
     # the warp stage of configs[4] (float32 in both modes) at 4K: zero control vectors -> identity grid

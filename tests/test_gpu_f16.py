@@ -286,6 +286,98 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
         _lib.call("dvsg_debug_set_option", b"wide16_hreuse", 1)
 
 
+def test_plain_float16_layers_on_the_wide_tiles():
+    """A layer WITHOUT the lo piece (`dvsg_conv_gemm_f16`; in the network: `f16_split=0` or a layer cleared in
+    `f16_pair_mask`) with Cout % 128 == 0 and Cin % 64 == 0 runs, from `wide16_min_tiles` tiles on, in the SPLIT = false
+    instantiations of conv_gemm_wide16.hip -- `acc_lo` holds channels 64..127 of a 128-channel tile and the epilogue
+    runs both halves.  Forced onto small ragged layers: against float32 math on the float16-rounded weights, and against
+    the 128 x 128 kernel (`conv_variant=5`), residual modes 0 / 1 / 2, with and without ReLU."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(15)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [  # k, stride, cin, cout, B, h, w, residual mode (0 none, 1 same shape, 2 subsampled input-sized), relu
+        (3, 2, 128, 128, 2, 23, 31, 0, 1), (1, 1, 256, 128, 5, 9, 13, 1, 0), (1, 1, 64, 256, 2, 37, 41, 2, 1),
+        (3, 1, 256, 256, 1, 16, 16, 1, 1), (3, 1, 64, 128, 2, 1, 300, 0, 0), (3, 1, 128, 128, 1, 127, 4, 1, 1),
+        (3, 1, 512, 128, 2, 30, 33, 0, 1), (1, 1, 128, 512, 3, 17, 19, 1, 1), (1, 1, 512, 128, 1, 1, 1, 0, 0),
+        (1, 2, 256, 512, 2, 21, 23, 0, 0), (3, 1, 64, 128, 5, 7, 5, 2, 1)]
+    try:
+        for k, stride, cin, cout, B, h, w, rmode, relu in cases:
+            K = k * k * cin
+            ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+            x = (torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3).half()
+            w16 = ((torch.rand((cout, K), generator=g, device=dev) - 0.5) * (2.0 / K ** 0.5)).half()
+            bias = torch.rand((cout,), generator=g, device=dev) - 0.5
+            res_stride = 1
+            if rmode == 1:
+                res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5).half()
+                res_at = res
+            elif rmode == 2:
+                res_stride = 2
+                res = (torch.rand((B, 2 * (ho - 1) + 1, 2 * (wo - 1) + 1, cout), generator=g, device=dev) - 0.5).half()
+                res_at = res[:, ::2, ::2, :]
+            else:
+                res, res_at = None, None
+            outs = {}
+            for key, variant, thr, arows in (("wide", 0, 1, 1), ("wide_rows64", 0, 1, 0), ("t128", 5, 128, 1)):
+                _lib.call("dvsg_debug_set_option", b"conv_variant", variant)
+                _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", thr)
+                _lib.call("dvsg_debug_set_option", b"wide16_arows", arows)
+                y = torch.full((B, ho, wo, cout), float("nan"), device=dev, dtype=torch.float16)
+                _lib.call("dvsg_conv_gemm_f16", x.data_ptr(), w16.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else 0,
+                          y.data_ptr(), B, h, w, cin, cout, k, stride, relu, res_stride, 0, 0, st)
+                outs[key] = y.float()
+            w4 = w16.float().reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+            ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+            if res_at is not None:
+                ref = ref + res_at.float()
+            if relu:
+                ref = torch.relu(ref)
+            scale = max(1.0, float(ref.abs().max()))
+            case = (k, stride, cin, cout, B, h, w, rmode, relu)
+            for key in ("wide", "wide_rows64", "t128"):
+                assert bool(torch.isfinite(outs[key]).all()), (key, case)
+                assert float((outs[key] - ref).abs().max()) < 1.2e-3 * scale, (key, case)     # float16 rounding of the output
+            assert float((outs["wide"] - outs["t128"]).abs().max()) < 1.0e-3 * scale, case   # one float16 ulp of the output
+            assert float((outs["wide"] - outs["t128"]).abs().mean()) < 2e-5 * scale, case
+            assert float((outs["wide_rows64"] - outs["t128"]).abs().mean()) < 2e-5 * scale, case
+    finally:
+        _lib.call("dvsg_debug_set_option", b"conv_variant", 0)
+        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 128)
+        _lib.call("dvsg_debug_set_option", b"wide16_arows", 1)
+
+
+def test_f16_pair_mask_through_the_wide_plain_tiles(net, synthetic_weights):
+    """A non-trivial `f16_pair_mask`: blocks 2-4 without the lo piece (0x1111 keeps block 1's four layer kinds), their
+    layers forced onto the wide plain-weight tiles.  F_t stays bounded against the oracle -- a broken SPLIT = false kernel
+    gives errors of O(|F|) -- and agrees with the same mask on the 128 x 128 kernels to float32 re-association + one
+    float16 rounding per activation."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    x = inputs.window_frames(331, 2, 96, 160)
+    F_ref = onet.localizationNet(x, 25, synthetic_weights)
+    xt = torch.from_numpy(x).cuda()
+    F = {}
+    try:
+        _lib.call("dvsg_debug_set_option", b"f16_pair_mask", 0x1111)
+        for key, variant, thr in (("wide", 0, 1), ("t128", 5, 128)):
+            _lib.call("dvsg_debug_set_option", b"conv_variant", variant)
+            _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", thr)
+            F[key] = net.forward(xt, precision="f16").cpu().numpy()
+    finally:
+        _lib.call("dvsg_debug_set_option", b"f16_pair_mask", 0xFFFF)
+        _lib.call("dvsg_debug_set_option", b"conv_variant", 0)
+        _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", 128)
+    full = net.forward(xt, precision="f16").cpu().numpy()
+    e_wide, e_128, e_full = (np.abs(v - F_ref).max() for v in (F["wide"], F["t128"], full))
+    print("f16_pair_mask 0x1111: F_t error wide plain tiles %.3g, 128x128 kernels %.3g, all pairs %.3g (|F| %.3g)"
+          % (e_wide, e_128, e_full, np.abs(F_ref).max()))
+    assert e_full < 5e-5
+    assert e_wide < 5e-4 and e_128 < 5e-4          # plain float16 weights cost ~10x the pairs' error, not more
+    assert np.abs(F["wide"] - F["t128"]).max() < 1e-4
+
+
 @pytest.mark.parametrize("source", ["window", "ring_f32", "ring_u8"])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 70, 100), (3, 33, 47), (1, 8, 8), (1, 1, 1), (2, 30, 600), (1, 100, 301)])
 def test_conv1_f16_kernels_agree(net, source, B, H, W):

@@ -249,3 +249,32 @@ def test_resnet_shapes_match_survey_appendix(synthetic_weights):
     assert taps["conv1"].shape == (1, 23, 40, 64) and taps["pool1"].shape == (1, 12, 20, 64)
     assert taps["block1/unit_3"].shape == (1, 6, 10, 256) and taps["block2/unit_4"].shape == (1, 3, 5, 512)
     assert taps["block3/unit_6"].shape == (1, 2, 3, 1024) and taps["block4/unit_3"].shape == (1, 2, 3, 2048)
+
+
+def test_float64_arbiter_is_the_same_map():
+    """oracle/thin_plate_spline.py `source_coords_f64` / `interpolate_a_f64` (the float64 arbiter of the 4K tests) against
+    the float32 restatement at a size where float32 noise is small, against SciPy's thin-plate RBF (an implementation
+    that shares nothing with either), and on the known answers: zero vectors give the unit grid, a uniform vector a shift."""
+    from scipy.interpolate import RBFInterpolator
+    B, H, W = 2, 40, 56
+    coord = inputs.v_src(B)
+    vec = inputs.control_vectors(901, B, scale=0.1)
+    rhs = (coord + vec).astype(np.float32)
+    xo, yo = otps.source_coords(otps.solve_system(coord, rhs), coord, H, W)
+    x64, y64 = otps.source_coords_f64(coord, rhs, H, W)
+    assert np.abs(x64 - xo).max() < 2e-5 and np.abs(y64 - yo).max() < 2e-5
+    xr, yr = otps.source_coords_f64(coord, rhs, H, W, rows=[3, 17])
+    assert np.array_equal(xr[:, :W], x64[:, 3 * W:4 * W]) and np.array_equal(yr[:, W:], y64[:, 17 * W:18 * W])
+    xl, yl = otps.meshgrid_xy(H, W)
+    pts = np.stack([np.tile(xl, H), np.repeat(yl, W)], 1).astype(np.float64)
+    rbf = RBFInterpolator(coord[0].astype(np.float64), rhs[0].astype(np.float64), kernel="thin_plate_spline", degree=1)(pts)
+    assert np.abs(rbf[:, 0] - x64[0]).max() < 2e-5 and np.abs(rbf[:, 1] - y64[0]).max() < 2e-5   # (r^2 log r vs d2 log(d2 + 1e-6))
+    x0, y0 = otps.source_coords_f64(coord, coord, H, W)
+    assert np.abs(x0[0] - pts[:, 0]).max() < 1e-12 and np.abs(y0[0] - pts[:, 1]).max() < 1e-12
+    xs, _ = otps.source_coords_f64(coord, (coord + np.float32([0.25, 0.0])).astype(np.float32), H, W)
+    assert np.abs(xs[0] - (pts[:, 0] + 0.25)).max() < 1e-12
+    U = inputs.smooth_frames(902, B, H, W)
+    a32 = otps.interpolate_a(U, xo, yo)
+    a64 = otps.interpolate_a_f64(U, x64, y64)
+    border = otps.border_discontinuity_mask(xo, yo, H, W, delta=1e-2)
+    assert np.abs(a64 - a32).max(axis=2)[~border].max() < 1e-4
