@@ -63,19 +63,21 @@ def gpu_windows(B, H, W, seed, dev, S=7):
     return x
 
 
-def pmc_traffic(cls, B, H, W, precision="f32"):
+def pmc_traffic(cls, B, H, W, precision="f32", kind="stabilize"):
     """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes
     (profiles/rNN*_traffic.json, written by tools/summarize_profiles.py from separate FETCH_SIZE /
     WRITE_SIZE runs of this same command with the gfx950 corrections of MI355X_MICROARCH.md).
     Counters cannot be read from inside the timed run, so this is the last profiled value of the SAME
     workload (batch, size, precision recorded in the file); None for any other shape."""
     import glob
-    want = {"batch": B, "height": H, "width": W, "precision": precision}
+    want = {"batch": B, "height": H, "width": W, "precision": precision, "kind": kind}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("workload", {"batch": 16, "height": 720, "width": 1280, "precision": "f32"}) != want:
+            have = dict(d.get("workload", {"batch": 16, "height": 720, "width": 1280, "precision": "f32"}))
+            have.setdefault("kind", "stabilize")
+            if have != want:
                 continue
             c = d["classes"].get(str(cls))
             if c:
@@ -116,11 +118,12 @@ def cpu_model():
 
 
 def cpu_baseline(weights, H, W, budget_s=20.0):
-    """CPU oracle ("port": torch-CPU CNN + NumPy TPS) on one 720p window at a time.  The CNN and the
-    warp are also timed apart (the warp is one NumPy thread: SURVEY.md 8d's warp-only baseline);
-    tools/cpu_baseline_full.py adds the B=16 pass, too long for a default bench run."""
+    """CPU oracle ("port": torch-CPU CNN + torch-CPU TPS warp, both on every usable core -- TF-CPU's Eigen back end is
+    multi-threaded too; round 3's one-thread NumPy warp understated the CPU) on one 720p window at a time.  The CNN and
+    the warp are also timed apart; tools/cpu_baseline_full.py adds the B=16 pass, too long for a default bench run
+    (profiles/r04_cpu_baseline.json)."""
     from oracle.cnn_torch import TorchLocNet
-    from oracle.thin_plate_spline import ThinPlateSpline as o_tps
+    from oracle.tps_torch import ThinPlateSpline as o_tps
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import inputs
     cores = usable_cores()
@@ -147,8 +150,8 @@ def cpu_baseline(weights, H, W, budget_s=20.0):
     med = float(np.median(times))
     return {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "cnn_ms_per_frame": 1e3 * float(np.median(cnn_t)), "warp_ms_per_frame": 1e3 * float(np.median(warp_t)),
-            "sample": "%d single-window (B=1, %dx%d) passes of the torch-CPU CNN (%d threads) + NumPy TPS oracle "
-                      "(1 thread) after 1 warm-up; median" % (len(times), W, H, cores)}
+            "sample": "%d single-window (B=1, %dx%d) passes of the torch-CPU CNN + torch-CPU TPS warp oracle (%d threads "
+                      "each) after 1 warm-up; median" % (len(times), W, H, cores)}
 
 
 def cpu_baseline_flow(H, W, budget_s=10.0):
@@ -197,6 +200,122 @@ def latency_mode(net, dev, sizes=((720, 1280), (288, 512)), n_frames=48):
                                  "frac_of_f32_mfma_peak": CNN_GFLOP_PER_FRAME[(H, W)] / dt / 1e3 / PEAK_F32_MFMA_TFLOPS}
         del frames, stab
     return out
+
+
+def roofline_object(cls, precision, prof, CB, H, W, kind="stabilize", bound=None):
+    """The `roofline` object of one kernel class from dvsg_prof_end's figures (summed hipEvent durations of its launches,
+    their count, algorithmic FLOPs and bytes) and the committed PMC traffic of the same workload."""
+    total_ms, launches, flops, nbytes = prof
+    if bound is None:
+        bound = "mfma" if cls in MFMA_CLASSES else "hbm"
+    if bound == "mfma":
+        achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
+        # f32s: three float16 MFMAs per float32-equivalent product; f16: two (hi / lo weights), priced on algorithmic FLOPs
+        peak = (PEAK_F32_MFMA_TFLOPS if precision == "f32" else
+                PEAK_F16_MFMA_TFLOPS / 3.0 if precision == "f32s" else PEAK_F16_MFMA_TFLOPS)
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
+    else:
+        achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS}
+    traffic, traffic_src = pmc_traffic(cls, CB, H, W, precision, kind)
+    roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                     "kernel": (KERNEL_CLASSES_F16.get(cls, KERNEL_CLASSES[cls]) if precision == "f16" else KERNEL_CLASSES[cls]),
+                     "launches": launches, "avg_launch_ms": total_ms / max(launches, 1),
+                     "algorithmic_per_launch": (flops if bound == "mfma" else nbytes) / max(launches, 1),
+                     "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
+    return roofline
+
+
+def prof_region(cls, fn, steps):
+    """Time `steps` calls of fn() (fenced) with the library's hipEvent hook armed for kernel class `cls`."""
+    from coupe.dvsg_amd import _lib
+    torch.cuda.synchronize()
+    _lib.call("dvsg_prof_begin", cls)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n, fl, by = ctypes.c_double(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    _lib.call("dvsg_prof_end", ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+    return dt, (ms.value, n.value, fl.value, by.value)
+
+
+def free_gib(dev):
+    free, _ = torch.cuda.mem_get_info(dev)
+    return free / 2.0 ** 30
+
+
+def make_flow_inputs(B, H, W, seed, dev):
+    """SURVEY.md 8d cfg 3: frames as cfg 2; flow ~ N(0, 4 px) smoothed by a 15-px box, 1 % of the pixels out of bounds."""
+    u_t = gpu_windows(B, H, W, 1234 + seed, dev, S=1)
+    g = torch.Generator(device=dev).manual_seed(4321 + seed)
+    flow = 4.0 * 15.0 * torch.randn((B, 2, H, W), generator=g, device=dev)
+    flow = F.avg_pool2d(flow, 15, stride=1, padding=7).permute(0, 2, 3, 1).contiguous()
+    oob = torch.rand((B, H, W, 1), generator=g, device=dev) < 0.01
+    flow = torch.where(oob, flow + (max(H, W) + 5.0), flow).contiguous()
+    return u_t, flow
+
+
+def cfg2_tf_warp(dev, steps, warmup):
+    """BASELINE.json configs[2] beside the line of record: B=64 1280x720 frames through `dvsg_flow_warp_f32`
+    (warp_with_optical_flow.py:96-176), cfg-3 flow, inputs resident in HBM.  Outside the timed region of the headline."""
+    from coupe.dvsg_amd import _lib
+    B, H, W = 64, 720, 1280
+    need = 4.0 * B * H * W * (3 + 2 + 3 + 3) * 3 / 2.0 ** 30      # frames, flow, two outputs; x3 for the generator's temporaries
+    if free_gib(dev) < need:
+        return {"skipped": "%.1f GiB free, %.1f needed" % (free_gib(dev), need)}
+    u_t, flow = make_flow_inputs(B, H, W, 0, dev)
+    outs = [torch.empty((B, H, W, 3), device=dev) for _ in range(2)]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(i):
+        _lib.call("dvsg_flow_warp_f32", u_t.data_ptr(), flow.data_ptr(), B, H, W, 3, outs[i & 1].data_ptr(), st)
+    for i in range(max(warmup, 2)):
+        run(i)
+    steps = max(steps, 20)
+    dt, prof = prof_region(7, run, steps)
+    return {"workload": "configs[2]: batch=64 1280x720 frames, optical-flow warp (warp_with_optical_flow.tf_warp), flow ~ N(0, 4 px) "
+                        "box-smoothed (15 px), 1 % of the pixels out of bounds",
+            "metric": "tf_warp frames/sec (1280x720 RGB)", "value": B * steps / dt, "unit": "frames/s", "dtype": "f32",
+            "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "roofline": roofline_object(7, "f32", prof, B, H, W, kind="tf_warp")}
+
+
+def cfg4_f16_4k(net, dev, steps, warmup):
+    """BASELINE.json configs[4] beside the line of record: B=32 3840x2160 windows, float16 mode (float16 activations,
+    hi / lo float16 weight pairs, float32 accumulation, float32 TPS / warp), ONE dvsg_stabilize_f16 call per step.
+    `roofline` is the class with the most time in this mode -- the 1x1 convolutions, HBM-bound."""
+    B, H, W = 32, 2160, 3840
+    ws_bytes = ctypes.c_size_t()
+    from coupe.dvsg_amd import _lib
+    _lib.call("dvsg_locnet_workspace_bytes", net.handle, B, H, W, ctypes.byref(ws_bytes))
+    inputs_gib = 4.0 * B * H * W * (21 + 3 + 3 + 3) / 2.0 ** 30
+    need = ws_bytes.value / 2.0 ** 30 + inputs_gib + 4.0 * 8 * H * W * 21 * 2 / 2.0 ** 30 + 4.0   # + one chunk of generator temporaries
+    if free_gib(dev) < need:
+        return {"skipped": "%.1f GiB free, %.1f needed" % (free_gib(dev), need)}
+    patches = torch.cat([gpu_windows(8, H, W, 400 + i, dev) for i in range(B // 8)], 0)
+    u_t = patches[..., 18:].contiguous()
+    outs = [torch.empty((B, H, W, 3), device=dev) for _ in range(2)]
+    F_t = torch.empty((B, 25, 2), device=dev)
+
+    def run(i):
+        net.stabilize(patches, u_t, outs[i & 1], F_t, precision="f16")
+    for i in range(max(1, min(warmup, 2))):
+        run(i)
+    steps = max(2, min(steps, 4))
+    dt, prof = prof_region(2, run, steps)
+    res = {"workload": "configs[4]: batch=32 3840x2160 7-frame windows, float16 mode, full CNN+TPS+bilinear warp, one call per step",
+           "metric": "stabilized frames/sec (3840x2160 RGB)", "value": B * steps / dt, "unit": "frames/s", "dtype": "f16",
+           "steps": steps, "ms_per_step": 1e3 * dt / steps, "workspace_gib": ws_bytes.value / 2.0 ** 30,
+           "tolerance": "warped pixels < 1e-3 against a float64 evaluation of the reference's definition on the synthetic "
+                        "checkpoint (tests/test_gpu_configs.py: 3.9e-4); NOT met on a stress checkpoint (tests/test_gpu_stress.py)",
+           "roofline": roofline_object(2, "f16", prof, B, H, W, bound="hbm")}
+    del patches, u_t, outs
+    net._ws = None          # give the 4K workspace back
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(n):
@@ -279,6 +398,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32s measurement reported beside the f32 line")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 clip-loop measurement reported beside the line")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the cfg2_tf_warp / cfg4_f16_4k objects (BASELINE configs[2] and configs[4]) reported beside the line")
     ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f16"],
                     help="f32 (default, the reference's arithmetic: the headline number); f32s: float32 storage / "
                          "accumulation with products from two float16 pieces per operand (dtype f32x2f16); f16: float16 "
@@ -349,13 +470,7 @@ def main():
     CB = args.call_batch or (B if world == 1 else 16)
     weights = net = patches = u_t = flow = None
     if flow_mode:
-        # SURVEY.md 8d cfg 3: frames as cfg 2; flow ~ N(0, 4 px) smoothed by a 15-px box, 1 % of the pixels out of bounds
-        u_t = gpu_windows(B, H, W, 1234 + rank, dev, S=1)
-        g = torch.Generator(device=dev).manual_seed(4321 + rank)
-        flow = 4.0 * 15.0 * torch.randn((B, 2, H, W), generator=g, device=dev)
-        flow = F.avg_pool2d(flow, 15, stride=1, padding=7).permute(0, 2, 3, 1).contiguous()
-        oob = torch.rand((B, H, W, 1), generator=g, device=dev) < 0.01
-        flow = torch.where(oob, flow + (max(H, W) + 5.0), flow).contiguous()
+        u_t, flow = make_flow_inputs(B, H, W, rank, dev)
     else:
         weights = make_synthetic_weights(seed=0)
         net = LocNet(weights)
@@ -452,25 +567,9 @@ def main():
     if rank == 0:
         frames = world * B * args.steps
         ms_per_step = 1e3 * elapsed / args.steps
-        total_ms, launches, flops, nbytes = prof
         cls = args.prof_class
-        if cls in MFMA_CLASSES:
-            achieved = flops / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0
-            # f32s: three float16 MFMAs per float32-equivalent product; f16: two (hi / lo weights), priced on algorithmic FLOPs
-            peak = (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else
-                    PEAK_F16_MFMA_TFLOPS / 3.0 if args.precision == "f32s" else PEAK_F16_MFMA_TFLOPS)
-            roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}
-        else:
-            achieved = nbytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": achieved / PEAK_HBM_GBS}
         # the profiled unit is one dvsg_stabilize call: CB windows (= B at one GPU, 16 of a rank's 64 at N > 1)
-        traffic, traffic_src = pmc_traffic(cls, CB, H, W, args.precision)
-        roofline.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "kernel": (KERNEL_CLASSES_F16.get(cls, KERNEL_CLASSES[cls]) if args.precision == "f16" else KERNEL_CLASSES[cls]), "launches": launches,
-                         "avg_launch_ms": total_ms / max(launches, 1),
-                         "algorithmic_per_launch": (flops if cls in MFMA_CLASSES else nbytes) / max(launches, 1),
-                         "algorithmic_bytes_per_launch": nbytes / max(launches, 1)})
+        roofline = roofline_object(cls, args.precision, prof, CB, H, W, kind="tf_warp" if flow_mode else "stabilize")
         if flow_mode:
             which = "configs[2]" if (B, H, W) == (64, 720, 1280) else "non-BASELINE shape"
         elif (B, H, W) == (16, 720, 1280):
@@ -530,6 +629,19 @@ def main():
                 line["latency"] = latency_mode(net, dev)
             except Exception as exc:   # noqa: BLE001
                 line["latency"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if (world == 1 and not flow_mode and args.precision == "f32" and not args.no_configs and args.source == "window"
+                and (B, H, W) == (16, 720, 1280)):
+            # the other single-GPU BASELINE configs in the driver's record, each in its own try, outside the timed region
+            # above and after its tensors are released; `value` / `config` / `dtype` of the line are configs[1]'s alone
+            del patches, u_t, outs
+            torch.cuda.empty_cache()
+            for key, leg in (("cfg2_tf_warp", lambda: cfg2_tf_warp(dev, args.steps, args.warmup)),
+                             ("cfg4_f16_4k", lambda: cfg4_f16_4k(net, dev, args.steps, args.warmup))):
+                try:
+                    line[key] = leg()
+                except Exception as exc:   # noqa: BLE001
+                    line[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_flow(H, W) if flow_mode else cpu_baseline(weights, H, W)
         print(json.dumps(line), flush=True)

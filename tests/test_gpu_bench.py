@@ -44,6 +44,22 @@ def test_bench_line_has_the_contract_fields():
     assert abs(lat["1280x720"]["achieved_tflops"] - 154.5 / lat["1280x720"]["ms_per_frame"]) < 1e-6
 
 
+def test_bench_default_line_carries_the_other_single_gpu_configs():
+    """The line the driver records (no workload flags) is BASELINE configs[1] and, beside it and outside its timed region,
+    carries configs[2] (B=64 720p tf_warp) and configs[4] (B=32 3840x2160, float16 mode), each with its own roofline."""
+    d = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-latency")
+    assert d["config"]["workload"].startswith("configs[1]") and d["dtype"] == "f32" and d["config"]["batch_per_gpu"] == 16
+    c2, c4 = d["cfg2_tf_warp"], d["cfg4_f16_4k"]
+    assert "error" not in c2 and "skipped" not in c2, c2
+    assert "error" not in c4 and "skipped" not in c4, c4
+    assert c2["workload"].startswith("configs[2]") and c2["roofline"]["bound"] == "hbm" and c2["roofline"]["kernel"] == "stn_kernel"
+    assert c2["value"] > 50000 and abs(c2["value"] - 64 / (c2["ms_per_step"] * 1e-3)) / c2["value"] < 1e-6
+    assert 0.2 < c2["roofline"]["frac"] < 1.0 and c2["roofline"]["launches"] == c2["steps"]
+    assert c4["workload"].startswith("configs[4]") and c4["dtype"] == "f16" and c4["roofline"]["bound"] == "hbm"
+    assert c4["value"] > 200 and abs(c4["value"] - 32 / (c4["ms_per_step"] * 1e-3)) / c4["value"] < 1e-6
+    assert c4["roofline"]["launches"] == 32 * c4["steps"] and 0.2 < c4["roofline"]["frac"] < 1.0
+
+
 def test_bench_other_kernel_classes_and_precision():
     d = _run("--steps", "1", "--warmup", "1", "--batch", "2", "--height", "96", "--width", "160", "--prof-class", "6",
              "--no-cpu-baseline", "--precision", "f16")

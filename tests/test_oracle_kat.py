@@ -278,3 +278,19 @@ def test_float64_arbiter_is_the_same_map():
     a64 = otps.interpolate_a_f64(U, x64, y64)
     border = otps.border_discontinuity_mask(xo, yo, H, W, delta=1e-2)
     assert np.abs(a64 - a32).max(axis=2)[~border].max() < 1e-4
+
+
+def test_torch_tps_port_is_the_numpy_restatement():
+    """oracle/tps_torch.py (the multi-threaded warp leg of bench.py's cpu_baseline) computes what the NumPy
+    restatement of ThinPlateSpline.py computes: grid within float32 evaluation noise, pixels outside the counted
+    border-discontinuity pixels."""
+    from oracle import tps_torch
+    B, H, W = 2, 40, 56
+    U = inputs.smooth_frames(911, B, H, W)
+    coord, vec = inputs.v_src(B), inputs.control_vectors(912, B, scale=0.1)
+    out, xs, ys = otps.ThinPlateSpline(U, coord, vec, (H, W))
+    tout, txs, tys = tps_torch.ThinPlateSpline(U, coord, vec, (H, W))
+    assert tout.shape == out.shape and tout.dtype == np.float32
+    assert np.abs(txs - xs).max() < 2e-5 and np.abs(tys - ys).max() < 2e-5
+    border = otps.border_discontinuity_mask(xs, ys, H, W, delta=1e-2).reshape(B, H, W)
+    assert np.abs(tout - out).max(axis=3)[~border].max() < 1e-4

@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 STEPS=4
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_f16_step -o f16 --output-format csv -- python3 bench.py --precision f16 --batch 32 --height 2160 --width 3840 --steps $STEPS --warmup 1 --no-cpu-baseline --no-secondary --no-latency "$@" > gpurun_out/prof_f16_step.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_f16_step -o f16 --output-format csv -- python3 bench.py --precision f16 --batch 32 --height 2160 --width 3840 --steps $STEPS --warmup 1 --no-cpu-baseline --no-secondary --no-latency --no-configs "$@" > gpurun_out/prof_f16_step.log 2>&1
 f=$(find gpurun_out/prof_f16_step -name "*kernel_stats.csv" | head -1)
 python3 - "$f" $STEPS <<'PY'
 import csv,sys

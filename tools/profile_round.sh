@@ -13,7 +13,7 @@ rm -rf "$OUT"
 mkdir -p "$OUT"
 # --no-secondary / --no-latency: the f32s leg and the batch-1 clip loop bench.py reports beside the f32 line must not be in
 # the profile (round 2 mixed the f32s launches into the f32 traffic file)
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-latency $*"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-latency --no-configs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \

@@ -122,8 +122,12 @@ def workload_of(flags):
     import shlex
     a = shlex.split(flags or "")
     get = lambda k, d: a[a.index(k) + 1] if k in a else d
-    return {"batch": int(get("--batch", 16)), "height": int(get("--height", 720)), "width": int(get("--width", 1280)),
-            "precision": get("--precision", "f32")}
+    kind = get("--workload", "stabilize")
+    w = {"batch": int(get("--batch", 64 if kind == "tf_warp" else 16)), "height": int(get("--height", 720)),
+         "width": int(get("--width", 1280)), "precision": get("--precision", "f32")}
+    if kind != "stabilize":
+        w["kind"] = kind          # bench.py --workload tf_warp (BASELINE configs[2]): class 7 only
+    return w
 
 
 def main(src, dst, tag, flags=""):
