@@ -43,7 +43,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 MFMA_CLASSES = (0, 1, 2, 8)
 KERNEL_CLASSES = {0: "conv1_kernel", 1: "conv_gemm_kernel<*,3,*>", 2: "conv_gemm_kernel<*,1,*>",
-                  3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "stn_kernel",
+                  3: "maxpool_kernel", 4: "head", 5: "tps_solve_kernel", 6: "tps_warp_kernel", 7: "flow_warp_strip_kernel / stn_kernel",
                   8: "conv3x3_1x1_kernel"}
 # the float16 mode's kernels of the same classes (big launches)
 KERNEL_CLASSES_F16 = {0: "conv1_f16_march_kernel", 1: "conv_wide16h_kernel / conv_wide16a_kernel<3,*>", 2: "conv_wide16a_kernel<1,*> / conv_wide16_kernel<1,*>",

@@ -50,6 +50,10 @@ int tps_warp_ring_impl(const void *pool, int pool_is_u8, int n_pool, const int *
                        long coord_bstride, const float *T, int B, int H, int W, int P, float *out, float *x_s, float *y_s,
                        void *stream);
 
+void set_flow_tiled(int v); // diagnostic (dvsg_debug_set_option "flow_tiled"): 0 = tf_warp by global gathers (stn_kernel<kFlow>)
+void set_flow_rounds(int v);
+void set_warp_xcd(int v);   // diagnostic (dvsg_debug_set_option "warp_xcd"): XCD-aware workgroup order of the sampler kernels
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dvsg

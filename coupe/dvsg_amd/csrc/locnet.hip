@@ -811,6 +811,18 @@ int dvsg_debug_set_option(const char *name, int value) {
     set_wide16_packed(value);
     return DVSG_OK;
   }
+  if (std::strcmp(name, "flow_tiled") == 0) {
+    set_flow_tiled(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "flow_rounds") == 0) {
+    set_flow_rounds(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "warp_xcd") == 0) {
+    set_warp_xcd(value);
+    return DVSG_OK;
+  }
   if (std::strcmp(name, "conv1_variant") == 0) {
     set_conv1_variant(value);
     return DVSG_OK;

@@ -17,6 +17,7 @@
 #include <cstdint>
 
 #include "common.h"
+#include "cnn_device.h"
 
 namespace dvsg {
 namespace {
@@ -290,7 +291,8 @@ struct TapsB<0> {  // generic channel count: the blend reads through the tap poi
 struct PadGeom {
   float w00, w01, w10, w11;
   bool v00, v01, v10, v11;
-  int xa, xb, ya, yb;
+  int xa, xb, ya, yb;   // tap coordinates clamped into the image (what an unconditional global load may touch)
+  int x0, y0;           // the lower tap in the zero-ringed image's coordinates (image pixel x0 - 1, y0 - 1), in [0, W + 1] / [0, H + 1]
 };
 __device__ __forceinline__ PadGeom padded_geom(int H, int W, float x, float y) {
   PadGeom g;
@@ -313,6 +315,7 @@ __device__ __forceinline__ PadGeom padded_geom(int H, int W, float x, float y) {
   g.v00 = vx0 && vy0; g.v01 = vx1 && vy0; g.v10 = vx0 && vy1; g.v11 = vx1 && vy1;
   g.xa = clampi(x0 - 1, 0, W - 1); g.xb = clampi(x1 - 1, 0, W - 1);
   g.ya = clampi(y0 - 1, 0, H - 1); g.yb = clampi(y1 - 1, 0, H - 1);
+  g.x0 = x0; g.y0 = y0;
   return g;
 }
 
@@ -513,6 +516,8 @@ struct StnParams {
   float *xs_out, *ys_out;
   int H, W, Cn, out_h, out_w, n;
   float step_x, step_y;
+  int nbx, nby;         // column blocks / row groups per image (the grid is one-dimensional: see stn_kernel)
+  int xcd;              // 1: each XCD takes a contiguous range of (image, row group, column block) -- diagnostic switch
 };
 
 template <int SRC, int C, int PPT>
@@ -520,7 +525,14 @@ __global__ __launch_bounds__(kThreads) void stn_kernel(StnParams p) {
   __shared__ float sc[2 * 64];   // elastic coefficients [2][n+3]
   __shared__ float ssrc[2 * 64]; // elastic source points [2][n]
   __shared__ float sth[9];
-  const int b = blockIdx.z;
+  // One-dimensional grid, decoded as (image, row group, column block) with the column block fastest.  The hardware deals
+  // consecutive workgroup ids round-robin over the 8 XCDs, and a row group's taps reach +- the flow's range into the rows
+  // of its neighbours: dealt that way every source line was fetched by ~3 different L2s (PMC, configs[2]: 2.65 GB fetched
+  // per launch for 1.18 GB of frames + flow; 6.1 TB/s of fabric traffic -- the kernel was bound by it).  xcd_remap gives
+  // each XCD a contiguous range of ids, i.e. whole bands of rows of whole images: neighbouring row groups share an L2.
+  const int id = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int bx = id % p.nbx, by = (id / p.nbx) % p.nby;
+  const int b = id / (p.nbx * p.nby);
   const int t = threadIdx.x;
   if (SRC == kAffine) {
     if (t < 6) sth[t] = p.a[(size_t)b * 6 + t];
@@ -541,8 +553,8 @@ __global__ __launch_bounds__(kThreads) void stn_kernel(StnParams p) {
     if (t < 2 * n) ssrc[(t / n) * 64 + t % n] = p.c[t];
     __syncthreads();
   }
-  const int j = blockIdx.x * kThreads + t;
-  const int i0 = blockIdx.y * PPT;
+  const int j = bx * kThreads + t;
+  const int i0 = by * PPT;
   if (j >= p.out_w) return;
   const float *img = p.im ? p.im + (size_t)b * p.H * p.W * p.Cn : nullptr;
   const float x_t = -1.0f + p.step_x * (float)j;
@@ -649,6 +661,202 @@ __global__ __launch_bounds__(kThreads) void mask_plane_kernel(const float *__res
       ((g.w00 * (g.v00 ? 1.f : 0.f) + g.w01 * (g.v01 ? 1.f : 0.f)) + g.w10 * (g.v10 ? 1.f : 0.f)) + g.w11 * (g.v11 ? 1.f : 0.f);
 }
 
+// ----------------------------------------------------------------------------------------
+// tf_warp (warp_with_optical_flow.py:96-176) on RGB frames with the source rows of a column strip STREAMED THROUGH LDS.
+//
+// stn_kernel<kFlow> gathers its 4 taps x 12 B per pixel straight from global memory: 16 `global_load_dwordx3` per
+// thread whose lanes are 12 bytes apart and -- the flow differs from pixel to pixel -- scattered over 2-4 image rows per
+// wave instruction.  The texture addresser works such an instruction off in 40 (constant flow) to 65 cycles (BASELINE
+// configs[2]'s flow): SQ_WAIT_INST_ANY, waves stalled at the ISSUE of memory instructions, is 56 % of the wave cycles
+// while the HBM-side traffic is the algorithmic one -- bound by the address path, not by HBM (3.4 TB/s of algorithmic
+// bytes; 5.5 with a constant flow).  (A first LDS form, round 4 -- 64 x 16 tiles that reduce the bounding box of their
+// taps and then stage it -- gave the same bits 25 % SLOWER: flow load -> reduction -> window load -> gather is three
+// dependent memory round trips per tile with 12 waves per CU, and the box of a 64 x 16 tile under this flow is 3.2 tiles.)
+//
+// Here a workgroup owns a strip of 128 output columns and marches down a band of rows, 8 at a time.  The source window
+// is FIXED relative to the step -- the step's rows and columns +- 12 pixels -- so nothing about it depends on the flow:
+// its rows stream through a ring of 41 LDS rows, each fetched once per strip as whole 16-byte chunks per lane (1 KB per
+// wave instruction), the 8 new rows and the flow of step s + 1 requested before step s is computed.  Taps inside the
+// window come from LDS; a pixel with a tap outside it (a flow beyond +- 12 px: 0.3 % of the pixels at sigma = 4) takes
+// its four taps from global memory as before; taps on the zero ring are never read.  Geometry (`padded_geom`) and blend
+// are the functions stn_kernel uses on the same values in the same order: the output is bit-identical.
+// ----------------------------------------------------------------------------------------
+constexpr int kFsThreads = 512;                            // 8 waves: 128 columns x 4 row pairs
+constexpr int kFsW = 128, kFsStep = 8, kFsPPT = 2;         // strip width, rows per step, rows per thread
+constexpr int kFsMX = 12, kFsMY = 12;                     // window margins, pixels
+constexpr int kFsCols = kFsW + 2 * kFsMX + 1;             // 153 pixels: taps x .. x + 1
+constexpr int kFsCpr = (kFsCols * 12 + 12 + 15) / 16;     // 116 chunks of 16 bytes per window row (up to 12 bytes of lead-in)
+constexpr int kFsLive = kFsStep + 2 * kFsMY + 1;          // 33 rows feed a step
+constexpr int kFsRing = kFsLive + kFsStep;                // 41: the next step's 8 new rows land beside them
+constexpr int kFsNew = (kFsStep * kFsCpr + kFsThreads - 1) / kFsThreads;   // 2 chunks per thread and step
+
+struct FlowStripParams {
+  const float *im;      // [B,H,W,3], 16-byte aligned
+  const float *flow;    // [B,H,W,2]
+  float *out;           // [B,H,W,3]
+  int H, W, B;
+  int nstrips, nbands, band_rows;   // per image; band_rows is a multiple of kFsStep
+  int xcd;
+};
+
+// a workgroup barrier that leaves global loads and stores in flight: __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier,
+// which put every step's store acknowledgements and prefetch latency back in front of the barrier (SQ_WAIT_ANY 65 %)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(kFsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void flow_warp_strip_kernel(FlowStripParams p) {
+  __shared__ __attribute__((aligned(16))) float ring[kFsRing * kFsCpr * 4];   // 76 KB: two workgroups (32 waves) per CU
+  const int t = threadIdx.x;
+  const int id = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int strip = id % p.nstrips, band = (id / p.nstrips) % p.nbands, b = id / (p.nstrips * p.nbands);
+  const int H = p.H, W = p.W;
+  const int c0 = strip * kFsW, wx0 = c0 - kFsMX;          // first window column (may be negative)
+  const int i_begin = band * p.band_rows, i_end = min(H, i_begin + p.band_rows);
+  const long img_pix = (long)b * H * W;
+  const long total_bytes = (long)p.B * H * W * 12;
+  const char *base = reinterpret_cast<const char *>(p.im);
+  const float *img = p.im + img_pix * 3;
+  const int j = c0 + (t & (kFsW - 1));
+  const int rg = t >> 7;
+  const bool col_ok = j < W;
+  const int jc = col_ok ? j : W - 1;
+  // lead-in (floats) of image row y's first chunk: ((img_pix + y W + wx0) * 3) mod 4, in 32-bit arithmetic
+  const int a4 = (int)((img_pix + wx0) & 3), w4 = W & 3;
+  const float xf = (float)j;
+
+  // chunk c of image row y of the window: the 16 bytes at floor16(byte offset of pixel (y, wx0)) + 16 c.  UNCONDITIONAL:
+  // a load under a branch makes hipcc wait for it at the end of the branch (`s_waitcnt vmcnt(0)` a dozen lines behind
+  // every prefetch: the first builds of this kernel waited for each chunk in turn).  The offset is clamped into the
+  // tensor instead: bytes in front of it are columns < 0 of its first row, never used; an aligned 16-byte chunk that holds
+  // the tensor's last valid byte ends at most 12 bytes behind it, inside the same page; chunks wholly behind it are not used.
+  const long last_chunk = (total_bytes - 1) & ~15L;
+  auto load_chunk = [&](int y, int c) __attribute__((always_inline)) -> floatx4 {
+    long off = (((img_pix + (long)y * W + wx0) * 12) & ~15L) + 16L * c;
+    off = off < 0 ? 0 : (off > last_chunk ? last_chunk : off);
+    return *reinterpret_cast<const floatx4 *>(base + off);
+  };
+  auto ring_slot = [&](int s) __attribute__((always_inline)) -> int { return s >= kFsRing ? s - kFsRing : s; };
+
+  // the whole ring starts finite: slots of rows / columns outside the image are read (and dropped by the blend's select)
+  for (int e = t; e < kFsRing * kFsCpr; e += kFsThreads) reinterpret_cast<floatx4 *>(ring)[e] = floatx4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  // prologue: the 33 rows of the first step, straight into ring slots 0..32
+  for (int e = t; e < kFsLive * kFsCpr; e += kFsThreads) {
+    const int r = e / kFsCpr, c = e - r * kFsCpr;
+    const int y = i_begin - kFsMY + r;
+    if (y >= 0 && y < H) reinterpret_cast<floatx4 *>(ring)[r * kFsCpr + c] = load_chunk(y, c);
+  }
+  // Two steps of prefetch, in registers: at the head of step s the 8 new source rows and the flow of step s + 2 are
+  // requested; the rows of step s + 1 (requested a step earlier) go into the ring at the end of step s.  Register sets
+  // rotate by compile-time index (nw[s & 1], fl[s & 3]; the loop is unrolled by four), so no copy ever waits on a load.
+  floatx4 nw[2][kFsNew];
+  float2 fl[4][kFsPPT];
+  auto issue = [&](int i_of_step, floatx4 (&rows)[kFsNew], float2 (&flw)[kFsPPT]) __attribute__((always_inline)) {
+    i_of_step = min(i_of_step, H - 1);                     // behind the band's last step: harmless repeats (no branch)
+#pragma unroll
+    for (int k = 0; k < kFsNew; ++k) {
+      const int e = min(t + kFsThreads * k, kFsStep * kFsCpr - 1);   // (the lanes behind the last chunk repeat it: no branch)
+      const int r = e / kFsCpr, c = e - r * kFsCpr;
+      const int y = i_of_step + kFsMY + 1 + r;             // the 8 rows that step adds to the window of the one before it
+      rows[k] = load_chunk(min(y, H - 1), c);              // rows behind the image: a copy of its last row, never committed
+    }
+    const int rn = i_of_step + rg * kFsPPT;
+    const float2 *fn = reinterpret_cast<const float2 *>(p.flow) + (img_pix + (long)min(rn, H - 1) * W + jc);
+#pragma unroll
+    for (int r = 0; r < kFsPPT; ++r) flw[r] = fn[rn + r < H ? (long)r * W : 0];
+  };
+  {
+    const int r_first = i_begin + rg * kFsPPT;
+    const float2 *fptr = reinterpret_cast<const float2 *>(p.flow) + (img_pix + (long)min(r_first, H - 1) * W + jc);
+#pragma unroll
+    for (int r = 0; r < kFsPPT; ++r) fl[0][r] = fptr[r_first + r < H ? (long)r * W : 0];
+  }
+  issue(i_begin + kFsStep, nw[1], fl[1]);
+  __syncthreads();
+
+  int s0 = 0;   // ring slot of row i0 - kFsMY
+  auto step = [&](int i0, floatx4 (&rows_issue)[kFsNew], float2 (&fl_issue)[kFsPPT], const floatx4 (&rows_commit)[kFsNew],
+                  const float2 (&flc)[kFsPPT]) __attribute__((always_inline)) {
+    issue(i0 + 2 * kFsStep, rows_issue, fl_issue);
+    // ---- step s from the ring.  Branch-free main path: geometry of both rows, then all their LDS reads, then the blends.
+    // A pixel with a tap outside the window reads the window's first pixel instead and is redone from global memory in
+    // the rare branch behind.
+    const int wy0 = i0 - kFsMY;                            // first window row of this step
+    PadGeom g[kFsPPT];
+    int ia[kFsPPT], ic[kFsPPT];
+    bool inwin[kFsPPT];
+#pragma unroll
+    for (int r = 0; r < kFsPPT; ++r) {
+      const int i = i0 + rg * kFsPPT + r;
+      const float x = xf + flc[r].x;                       // :117-119
+      const float y = (float)i + flc[r].y;
+      g[r] = padded_geom(H, W, x, y);
+      // The taps are image pixels (xl, yl), (xl + 1, yl), (xl, yl + 1), (xl + 1, yl + 1) with xl = x0 - 1 in [-1, W]; those
+      // outside the image are on the zero ring: read from the window like the others (its slots there hold finite
+      // bytes) and dropped by the blend's select.  All four inside the window?
+      const int xl = g[r].x0 - 1, yl = g[r].y0 - 1;
+      int dx = xl - wx0, dy = yl - wy0;
+      inwin[r] = (unsigned)dx <= (unsigned)(kFsCols - 2) && (unsigned)dy <= (unsigned)(kFsLive - 2);
+      dx = inwin[r] ? dx : 0;
+      dy = inwin[r] ? dy : 0;
+      const int yy = wy0 + dy;
+      const int sa = ring_slot(s0 + dy), sb = ring_slot(s0 + dy + 1);
+      ia[r] = sa * (kFsCpr * 4) + (((a4 + yy * w4) * 3) & 3) + dx * 3;
+      ic[r] = sb * (kFsCpr * 4) + (((a4 + (yy + 1) * w4) * 3) & 3) + dx * 3;
+    }
+    TapsB<3> tp[kFsPPT];
+#pragma unroll
+    for (int r = 0; r < kFsPPT; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        tp[r].a.v[c] = ring[ia[r] + c];
+        tp[r].b.v[c] = ring[ia[r] + 3 + c];
+        tp[r].c.v[c] = ring[ic[r] + c];
+        tp[r].d.v[c] = ring[ic[r] + 3 + c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kFsPPT; ++r) {
+      const int i = i0 + rg * kFsPPT + r;
+      tp[r].w00 = g[r].w00; tp[r].w01 = g[r].w01; tp[r].w10 = g[r].w10; tp[r].w11 = g[r].w11;
+      tp[r].v00 = g[r].v00; tp[r].v01 = g[r].v01; tp[r].v10 = g[r].v10; tp[r].v11 = g[r].v11;
+      if (!inwin[r] && (g[r].v00 || g[r].v01 || g[r].v10 || g[r].v11) && col_ok && i < i_end) {
+        // a flow beyond the margins: global gathers, as stn_kernel
+        tp[r].a = load_pix<3>(img + ((long)g[r].ya * W + g[r].xa) * 3);
+        tp[r].b = load_pix<3>(img + ((long)g[r].ya * W + g[r].xb) * 3);
+        tp[r].c = load_pix<3>(img + ((long)g[r].yb * W + g[r].xa) * 3);
+        tp[r].d = load_pix<3>(img + ((long)g[r].yb * W + g[r].xb) * 3);
+      }
+      float v[3];
+      sample_padded_blend<3>(tp[r], 3, v);
+      if (col_ok && i < i_end) store_pix<3>(p.out, (size_t)(img_pix + (long)i * W + j), 3, v);
+    }
+    // ---- the rows of step s + 1 (requested at the head of step s - 1) into the slots beside the live ones (last read in
+    // step s - 1, behind that step's barrier)
+    if (i0 + kFsStep < i_end) {
+      const int snew = ring_slot(s0 + kFsLive);
+#pragma unroll
+      for (int k = 0; k < kFsNew; ++k) {
+        const int e = t + kFsThreads * k;
+        const int r = e / kFsCpr, c = e - r * kFsCpr;
+        const int y = i0 + kFsStep + kFsMY + 1 + r;
+        if (e < kFsStep * kFsCpr && y < H) reinterpret_cast<floatx4 *>(ring)[ring_slot(snew + r) * kFsCpr + c] = rows_commit[k];
+      }
+    }
+    s0 = ring_slot(s0 + kFsStep);
+    lds_barrier();
+  };
+  for (int i0 = i_begin; i0 < i_end; i0 += 4 * kFsStep) {   // (every thread of the workgroup takes the same exits)
+    step(i0, nw[0], fl[2], nw[1], fl[0]);
+    if (i0 + kFsStep >= i_end) break;
+    step(i0 + kFsStep, nw[1], fl[3], nw[0], fl[1]);
+    if (i0 + 2 * kFsStep >= i_end) break;
+    step(i0 + 2 * kFsStep, nw[0], fl[0], nw[1], fl[2]);
+    if (i0 + 3 * kFsStep >= i_end) break;
+    step(i0 + 3 * kFsStep, nw[1], fl[1], nw[0], fl[3]);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void scale_rgb_kernel(const float *__restrict__ in,
                                                             float *__restrict__ out, size_t npix,
                                                             int C) {
@@ -668,10 +876,19 @@ __global__ __launch_bounds__(kThreads) void scale_rgb_kernel(const float *__rest
 
 inline float lin_step(int n) { return n > 1 ? (1.0f - (-1.0f)) / (float)(n - 1) : 0.0f; }
 
+int g_flow_tiled = 1;  // dvsg_debug_set_option("flow_tiled", v): 0 = stn_kernel<kFlow> (global gathers), 1 = column strips streamed
+                       // through LDS, workgroups in XCD-aware order (default), 2 = the same in plain dispatch order
+int g_flow_rounds = 4; // rounds of resident workgroups the strip kernel's bands aim at ("flow_rounds")
+int g_warp_xcd = 0;   // dvsg_debug_set_option("warp_xcd", 0): the samplers' workgroups in plain dispatch order (A/B)
+
 template <int SRC>
 int launch_stn(StnParams p, int B, hipStream_t s, const char *what) {
   constexpr int PPT = (SRC == kFlow || SRC == kCoords) ? 4 : 2;  // memory-fed coordinates: more loads in flight per thread
-  dim3 grid(ceil_div(p.out_w, kThreads), ceil_div(p.out_h, PPT), B);
+  p.nbx = ceil_div(p.out_w, kThreads);
+  p.nby = ceil_div(p.out_h, PPT);
+  p.xcd = g_warp_xcd;
+  DVSG_REQUIRE((long)p.nbx * p.nby * B < (1L << 31), "%s: grid of %ld workgroups out of range", what, (long)p.nbx * p.nby * B);
+  dim3 grid((unsigned)(p.nbx * p.nby * B));
   // algorithmic bytes per output pixel: read C + write C floats (+ flow 8 B / coords 8 B)
   const double px = (double)B * p.out_h * p.out_w;
   ProfScope prof(kClsStn, s, 0.0,
@@ -696,6 +913,10 @@ int check_image_args(const char *fn, int B, int H, int W, int C, int out_h, int 
 }
 
 }  // namespace
+
+void set_warp_xcd(int v) { g_warp_xcd = v != 0; }
+void set_flow_tiled(int v) { g_flow_tiled = v; }
+void set_flow_rounds(int v) { g_flow_rounds = v > 0 ? v : 1; }
 
 // coord_bstride = 0 broadcasts one set of control points over the batch (model.py:111 tiles
 // the constant V_src; the fused evaluation graph does not materialise the tile).
@@ -825,6 +1046,26 @@ int dvsg_flow_warp_f32(const float *im, const float *flow, int B, int H, int W, 
                        void *stream) {
   DVSG_REQUIRE(im && flow && out, "dvsg_flow_warp_f32: NULL pointer");
   if (int rc = check_image_args("dvsg_flow_warp_f32", B, H, W, C, H, W)) return rc;
+  if (C == 3 && g_flow_tiled && reinterpret_cast<uintptr_t>(im) % 16 == 0) {
+    // RGB frames: the source rows of a column strip streamed through LDS (flow_warp_strip_kernel); same bits as stn_kernel<kFlow>
+    FlowStripParams q{};
+    q.im = im; q.flow = flow; q.out = out;
+    q.H = H; q.W = W; q.B = B;
+    q.nstrips = ceil_div(W, kFsW);
+    // bands: enough workgroups for >= 4 rounds of the 512 resident ones, bands of >= 64 rows (a band primes 33 rows)
+    const int steps = ceil_div(H, kFsStep);
+    int bands = (int)std::min<long>(std::max<long>(1, ((long)g_flow_rounds * 512 + (long)q.nstrips * B - 1) / ((long)q.nstrips * B)), std::max(1, steps / 8));
+    const int band_steps = ceil_div(steps, bands);
+    q.band_rows = band_steps * kFsStep;
+    q.nbands = ceil_div(H, q.band_rows);
+    q.xcd = g_flow_tiled != 2;
+    const long wgs = (long)q.nstrips * q.nbands * B;
+    DVSG_REQUIRE(wgs < (1L << 31), "dvsg_flow_warp_f32: grid of %ld workgroups out of range", wgs);
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(kClsStn, s, 0.0, 32.0 * B * H * W);
+    hipLaunchKernelGGL(flow_warp_strip_kernel, dim3((unsigned)wgs), dim3(kFsThreads), 0, s, q);
+    return check_launch("flow_warp_strip_kernel");
+  }
   StnParams p{};
   p.im = im; p.a = flow; p.out = out;
   p.H = H; p.W = W; p.Cn = C; p.out_h = H; p.out_w = W;

@@ -359,7 +359,8 @@ int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, c
  * "fuse_shortcut", "f16_split", "f16_pair_mask", and for the float16 mode's big launches "wide16_min_tiles" (tiles from
  * which the 256 x 128 geometry runs: 128), "wide16_packed" / "wide16_arows" / "wide16_hreuse" / "fused_hreuse" (1: weight
  * stages from the packed copy, 128-byte activation rows, a 3x3 kernel row's taps from one staged run, the same in block 1's
- * fused kernel; 0 selects the kernel each replaced).  Results do not depend on them beyond float32 re-association. */
+ * fused kernel; 0 selects the kernel each replaced), "warp_xcd" (0: the sampler kernels' workgroups in plain dispatch order).
+ * Results do not depend on them beyond float32 re-association. */
 int dvsg_debug_set_option(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------

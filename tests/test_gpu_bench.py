@@ -52,8 +52,8 @@ def test_bench_default_line_carries_the_other_single_gpu_configs():
     c2, c4 = d["cfg2_tf_warp"], d["cfg4_f16_4k"]
     assert "error" not in c2 and "skipped" not in c2, c2
     assert "error" not in c4 and "skipped" not in c4, c4
-    assert c2["workload"].startswith("configs[2]") and c2["roofline"]["bound"] == "hbm" and c2["roofline"]["kernel"] == "stn_kernel"
-    assert c2["value"] > 50000 and abs(c2["value"] - 64 / (c2["ms_per_step"] * 1e-3)) / c2["value"] < 1e-6
+    assert c2["workload"].startswith("configs[2]") and c2["roofline"]["bound"] == "hbm" and "flow_warp_strip_kernel" in c2["roofline"]["kernel"]
+    assert c2["value"] > 100000 and c2["roofline"]["traffic"] and abs(c2["value"] - 64 / (c2["ms_per_step"] * 1e-3)) / c2["value"] < 1e-6
     assert 0.2 < c2["roofline"]["frac"] < 1.0 and c2["roofline"]["launches"] == c2["steps"]
     assert c4["workload"].startswith("configs[4]") and c4["dtype"] == "f16" and c4["roofline"]["bound"] == "hbm"
     assert c4["value"] > 200 and abs(c4["value"] - 32 / (c4["ms_per_step"] * 1e-3)) / c4["value"] < 1e-6
@@ -76,7 +76,7 @@ def test_bench_f32s_precision_is_separately_named():
 def test_bench_tf_warp_workload():
     d = _run("--workload", "tf_warp", "--steps", "2", "--warmup", "1", "--batch", "3", "--height", "96", "--width", "160")
     assert d["metric"].startswith("tf_warp") and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
-    assert d["roofline"]["kernel"] == "stn_kernel" and d["roofline"]["launches"] == 2 and d["cpu_baseline"]["cores"] == 1
+    assert "stn_kernel" in d["roofline"]["kernel"] and d["roofline"]["launches"] == 2 and d["cpu_baseline"]["cores"] == 1
 
 
 def test_bench_rccl_calls_of_the_sharded_path_run_on_one_rank():

@@ -197,6 +197,53 @@ def test_tf_warp_matches_oracle(dev, B, H, W, C):
     assert np.abs(out - ref).max() <= 1e-6
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 53), (1, 8, 128), (1, 9, 129), (3, 64, 300), (1, 1, 1), (2, 5, 4), (1, 200, 131),
+                                   (2, 180, 320), (1, 720, 1280)])
+def test_tf_warp_strip_kernel_gives_the_gather_kernel_bits(dev, B, H, W):
+    """`dvsg_flow_warp_f32` on RGB frames streams the source rows of a 128-column strip through an LDS ring (window: the step
+    +- 12 px) and takes the taps from there; a pixel whose flow leaves the window gathers from global memory.  Same geometry
+    and blend functions on the same values as the gather kernel (`flow_tiled` = 0): the SAME BITS -- for the smooth flow
+    of BASELINE configs[2], white noise, a constant flow, a flow that leaves the margins everywhere, flows that point at
+    and beyond every image border, and NaN / Inf free results on all of them; also against the oracle (<= 1e-6)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    rng = np.random.default_rng(1000 * H + W)
+    im = torch.from_numpy(inputs.smooth_frames(53, B, H, W, 3)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    flows = {"cfg3": inputs.smooth_flow(54, B, H, W),
+             "noise": (4.0 * rng.standard_normal((B, H, W, 2))).astype(np.float32),
+             "const": np.broadcast_to(np.float32([3.3, -1.7]), (B, H, W, 2)).copy(),
+             "wide": (40.0 * rng.standard_normal((B, H, W, 2))).astype(np.float32),            # beyond the +- 12 px window
+             "edges": np.stack([rng.uniform(-W - 3, W + 3, (B, H, W)), rng.uniform(-H - 3, H + 3, (B, H, W))], -1).astype(np.float32),
+             "integer": np.rint(6.0 * rng.standard_normal((B, H, W, 2))).astype(np.float32)}
+    for name, f in flows.items():
+        fl = torch.from_numpy(f).to(dev)
+        outs = {}
+        try:
+            for v in (0, 1, 2):
+                _lib.call("dvsg_debug_set_option", b"flow_tiled", v)
+                out = torch.full((B, H, W, 3), float("nan"), device=dev)
+                _lib.call("dvsg_flow_warp_f32", im.data_ptr(), fl.data_ptr(), B, H, W, 3, out.data_ptr(), st)
+                outs[v] = out
+        finally:
+            _lib.call("dvsg_debug_set_option", b"flow_tiled", 1)
+        assert bool(torch.isfinite(outs[1]).all()), name
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), (name, float((outs[1] - outs[0]).abs().max()))
+        if H * W <= 64 * 300:
+            assert np.abs(outs[1].cpu().numpy() - oflow.tf_warp(im.cpu().numpy(), f, H, W)).max() <= 1e-6, name
+    # a frame tensor off the 16-byte grid takes the gather kernel (the strip kernel's chunks are aligned loads): same result
+    if H * W >= 4:
+        buf = torch.empty(B * H * W * 3 + 1, device=dev)
+        view = buf[1:].reshape(B, H, W, 3)
+        view.copy_(im)
+        fl = torch.from_numpy(flows["cfg3"]).to(dev)
+        out = torch.empty((B, H, W, 3), device=dev)
+        ref = torch.empty((B, H, W, 3), device=dev)
+        _lib.call("dvsg_flow_warp_f32", view.data_ptr(), fl.data_ptr(), B, H, W, 3, out.data_ptr(), st)
+        _lib.call("dvsg_flow_warp_f32", im.data_ptr(), fl.data_ptr(), B, H, W, 3, ref.data_ptr(), st)
+        assert torch.equal(out, ref)
+
+
 def test_tf_warp_known_answers(dev):
     """SURVEY.md 8c (1)-(3)."""
     from coupe.dvsg_amd.warp_with_optical_flow import tf_warp

@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 CLASSES = {"conv1_kernel": 0, "conv1_f16_kernel": 0, "conv1_f16_pair_kernel": 0, "conv1_f16_march_kernel": 0, "conv1_split_kernel": 0, "maxpool_p_kernel": 3, "maxpool_h8_kernel": 3, "avgpool_partial_p_kernel": 4, "conv_gemm": None, "maxpool_kernel": 3, "tps_solve_kernel": 5, "tps_warp_kernel": 6,
-           "stn_kernel": 7, "dense_kernel": 4, "avgpool_partial_kernel": 4, "dense_finalize_kernel": 4}
+           "stn_kernel": 7, "flow_warp_strip_kernel": 7, "mask_plane_kernel": 7, "dense_kernel": 4, "avgpool_partial_kernel": 4, "dense_finalize_kernel": 4}
 
 
 def short(n):
