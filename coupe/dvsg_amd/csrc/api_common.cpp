@@ -37,23 +37,27 @@ struct Prof {
   std::atomic<int> cls{-1};
   std::mutex mu;
   std::vector<hipEvent_t> start, stop;
+  std::vector<hipEvent_t> pool;   // events made by dvsg_prof_begin (and handed back by dvsg_prof_end): a profiled launch
+                                  // inside a timed region costs two hipEventRecord, no hipEventCreate / Destroy
   double flops = 0, bytes = 0;
 } g_prof;
+constexpr size_t kProfPoolEvents = 2048;   // 1024 launches per armed region without a creation
 }  // namespace
 
 ProfScope::ProfScope(int cls, hipStream_t s, double flops, double bytes) : idx_(-1), s_(s) {
   if (cls != g_prof.cls.load(std::memory_order_relaxed)) return;
-  hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess) return;
-  if (hipEventCreate(&b) != hipSuccess) {
-    (void)hipEventDestroy(a);
-    return;
-  }
   std::lock_guard<std::mutex> lock(g_prof.mu);
-  if (cls != g_prof.cls.load(std::memory_order_relaxed)) {  // disarmed meanwhile
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    return;
+  if (cls != g_prof.cls.load(std::memory_order_relaxed)) return;  // disarmed meanwhile
+  hipEvent_t a, b;
+  if (g_prof.pool.size() >= 2) {
+    a = g_prof.pool.back(); g_prof.pool.pop_back();
+    b = g_prof.pool.back(); g_prof.pool.pop_back();
+  } else {   // a region of more launches than the pool holds: create (and keep) more
+    if (hipEventCreate(&a) != hipSuccess) return;
+    if (hipEventCreate(&b) != hipSuccess) {
+      (void)hipEventDestroy(a);
+      return;
+    }
   }
   stop_ = b;
   g_prof.start.push_back(a);
@@ -74,6 +78,11 @@ int dvsg_prof_begin(int kernel_class) {
                kernel_class, dvsg::kNumCls);
   std::lock_guard<std::mutex> lock(dvsg::g_prof.mu);
   DVSG_REQUIRE(dvsg::g_prof.cls.load() < 0, "dvsg_prof_begin: profiling already armed");
+  while (dvsg::g_prof.pool.size() < dvsg::kProfPoolEvents) {   // once per process in practice: dvsg_prof_end hands them back
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) break;
+    dvsg::g_prof.pool.push_back(e);
+  }
   dvsg::g_prof.flops = dvsg::g_prof.bytes = 0;
   dvsg::g_prof.cls.store(kernel_class);
   return DVSG_OK;
@@ -92,8 +101,8 @@ int dvsg_prof_end(double *total_ms, int *launches, double *flops, double *bytes)
         hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]) != hipSuccess)
       rc = dvsg::fail(DVSG_ERR_HIP, "dvsg_prof_end: event query failed");
     ms += t;
-    (void)hipEventDestroy(g_prof.start[i]);
-    (void)hipEventDestroy(g_prof.stop[i]);
+    g_prof.pool.push_back(g_prof.start[i]);
+    g_prof.pool.push_back(g_prof.stop[i]);
   }
   if (total_ms) *total_ms = ms;
   if (launches) *launches = (int)g_prof.start.size();

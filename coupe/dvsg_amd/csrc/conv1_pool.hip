@@ -1058,6 +1058,11 @@ void conv1_f16_march_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1
       typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
       _Float16 *base = reinterpret_cast<_Float16 *>(in_s) + slot_of(input_row);
       if constexpr (Row::kRing) {
+        // element 0 is the zero tap's slot: the scatter never writes it, but `flush_quad` below transposes conv1 OUTPUTS
+        // through halves [0, 5120) of the even ring slots -- a stale output there meets a zero weight and must be finite;
+        // a float16 output that overflowed to inf would turn the tile's first pixel of a later quad into NaN.  One lane
+        // rewrites it with every staged row (the window path below rewrites the whole segment anyway).
+        if (st == 0) base[0] = (_Float16)0.f;
         row.scatter(dd, [&](int e, float v) __attribute__((always_inline)) { base[e] = (_Float16)v; });
       } else {
         half4_t *dst = reinterpret_cast<half4_t *>(base);

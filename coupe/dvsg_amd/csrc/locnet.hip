@@ -551,7 +551,9 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
     if (int rc = launch_zero_tickets(static_cast<int *>(scratch), cbytes / sizeof(int), as_stream(stream))) return rc;
     p.splitk_counters = static_cast<int *>(scratch);
     p.splitk_scratch = static_cast<char *>(scratch) + cbytes;
-    p.splitk_scratch_bytes = scratch_bytes - cbytes;
+    // the partial-tile slabs own at most kSplitKSlabBytes behind the tickets: whatever the caller's scratch holds beyond
+    // that may carry the packed weight copies below, which a slab user sizing itself by this field must never reach
+    p.splitk_scratch_bytes = std::min(scratch_bytes - cbytes, align256(kSplitKSlabBytes));
   }
   if (prec == kF16 && wsplit && Cin % 64 == 0 && Cout % 64 == 0 && (ksize == 1 || ksize == 3) && scratch) {
     // the packed weight copies conv_gemm_wide16.hip prefers (what dvsg_locnet_create makes once per layer), made here on

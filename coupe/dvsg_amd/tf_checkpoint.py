@@ -180,7 +180,9 @@ def _shape_proto(shape):
 def _read_block(data, offset, size, verify=True):
     raw = data[offset:offset + size]
     ctype = data[offset + size]
-    if verify:
+    # the checksum is a byte-wise pure-Python CRC-32C: blocks beyond _VERIFY_DATA_LIMIT (the data blocks of a V1 file,
+    # which hold the tensors themselves -- ~100 MB for resnet_v1_50) are only checked with verify="all"
+    if verify and (verify == "all" or size <= _VERIFY_DATA_LIMIT):
         want = struct.unpack("<I", data[offset + size + 1:offset + size + 5])[0]
         if masked_crc(data[offset:offset + size + 1]) != want:
             raise ValueError("table block at %d: checksum mismatch" % offset)
@@ -349,6 +351,7 @@ def _tensor_proto(buf):
     int_val = 7, int64_val = 10, half_val = 13 (packed or repeated)."""
     dtype, shape, content = 0, (), None
     vals = {5: [], 6: [], 7: [], 10: [], 13: []}
+    packed = {5: [], 6: []}        # packed float_val / double_val runs stay NumPy arrays (one Python object per RUN, not per weight)
     for f, wt, v in _proto_fields(buf):
         if f == 1:
             dtype = v
@@ -359,9 +362,9 @@ def _tensor_proto(buf):
         elif f in vals:
             if wt == 2:                                   # packed
                 if f == 5:
-                    vals[f].extend(np.frombuffer(v, "<f4"))
+                    packed[5].append(np.frombuffer(v, "<f4"))
                 elif f == 6:
-                    vals[f].extend(np.frombuffer(v, "<f8"))
+                    packed[6].append(np.frombuffer(v, "<f8"))
                 else:
                     p = 0
                     while p < len(v):
@@ -379,6 +382,9 @@ def _tensor_proto(buf):
     n = int(np.prod(shape)) if shape else 1
     if content is not None and len(content):
         return np.frombuffer(content, np_dt.newbyteorder("<")).reshape(shape).astype(np_dt)
+    for f in (5, 6):               # repeated (unpacked) values first, then the packed runs, as they were appended
+        if packed[f]:
+            vals[f] = np.concatenate([np.asarray(vals[f], dtype=packed[f][0].dtype)] + packed[f])
     src = {1: vals[5], 2: vals[6], 3: vals[7], 9: vals[10], 19: vals[13]}[dtype]
     if dtype == 19:
         a = np.array(src, dtype=np.uint16).view(np.float16)
@@ -435,8 +441,10 @@ def write_v1(path, arrays):
 # ------------------------------------------------------------------------------------------------ public
 def load_checkpoint(path, verify=True):
     """{variable name: ndarray} from a TF checkpoint: `path` is a V2 prefix (`path.index` exists) or a V1 file.
-    verify: True checks every table block's CRC-32C and the payload checksum of tensors up to 1 MiB (pure-Python CRC);
-    "all" checks every payload; False checks nothing."""
+    verify: True checks the CRC-32C of every table block and tensor payload of up to 1 MiB (the checksum is a byte-wise
+    pure-Python loop; in a V1 file the tensors sit INSIDE table blocks, so its large data blocks -- ~100 MB for
+    resnet_v1_50 -- go unchecked, like a bundle's large payloads); "all" checks everything (minutes on such a file);
+    False checks nothing."""
     if os.path.isfile(path + ".index"):
         return _read_bundle(path, verify)
     if os.path.isfile(path):
