@@ -69,6 +69,8 @@ SIGNATURES = {
     "dvsg_frames_f32_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_frames_f64_to_u8": [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dvsg_debug_set_option": [ctypes.c_char_p, _i],
+    "dvsg_debug_calibrate_f16_weights": [_vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
+    "dvsg_locnet_calibrate_f16": [_vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_markers_enabled": [],
     "dvsg_prof_begin": [_i],
     "dvsg_prof_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double),

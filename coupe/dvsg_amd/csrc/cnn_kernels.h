@@ -90,6 +90,7 @@ struct ConvFused {
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize);
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s);
 void set_fuse_conv(int v);
+int get_fuse_conv();
 void set_fused_hreuse(int v);        // diagnostic (dvsg_debug_set_option "fused_hreuse")
 void set_conv_variant(int v);   // diagnostic A/B switches (dvsg_debug_set_option)
 void set_conv1_variant(int v);

@@ -903,6 +903,7 @@ int g_fuse_conv = 1;  // dvsg_debug_set_option("fuse_conv", 0) turns the fused b
 }  // namespace
 
 void set_fuse_conv(int v) { g_fuse_conv = v; }
+int get_fuse_conv() { return g_fuse_conv; }
 void set_fused_hreuse(int v) { g_fused_hreuse = v; }
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize) {
   if (prec == kF16) return g_fuse_conv != 0 && ksize == 3 && Cmid == CMID && Cin % 64 == 0 && Cout % 64 == 0;

@@ -36,6 +36,8 @@ struct ConvLayer {
   _Float16 *wt16p = nullptr;  // device, wt16s packed stage by stage for conv_gemm_wide16.hip (cin % 64 == 0 layers)
   _Float16 *wt16pa = nullptr; // device, the same in the order of its 128-byte-activation-row kernel
   _Float16 *wt16ph = nullptr; // device, the same in the order of its 3x3 stride-1 kernel (3x3 layers only)
+  _Float16 *wt16q = nullptr, *wt16qa = nullptr, *wt16qh = nullptr;   // device, the PLAIN copy wt16 packed the same three ways
+                              // (cin % 64 == 0, cout % 128 == 0 layers: what runs when a layer has no lo piece)
   _Float16 *wt32s = nullptr;  // device, "f32s" pieces [cout][k*k*cin/32][32 hi | 32 lo] (conv_gemm.hip SPLIT, T = float; not for conv1)
   float *bias = nullptr;      // device, [cout] float32
   const void *weights(int prec, bool split) const {
@@ -71,6 +73,9 @@ struct dvsg_locnet {
   float *dense_b[4] = {nullptr, nullptr, nullptr, nullptr};
   float *v_src = nullptr;  // [25,2] model.py:105-110
   double *winv = nullptr;  // [25][28]: columns of the TPS system's inverse for v_src (see tps_apply_kernel)
+  // float16 mode: which layers multiply by hi / lo weight PAIRS (bit 4 * kind + block, see g_f16_pair_mask).  All of them
+  // until dvsg_locnet_calibrate_f16 has re-rounded the plain copies of blocks 2-4 with error feedback: then block 1 only.
+  int f16_pair_mask = 0xFFFF;
   std::vector<void *> allocs;
 };
 
@@ -124,6 +129,30 @@ int bn_fold(const ArrayMap &m, const std::string &scope, int c, std::vector<floa
     (*scale)[i] = inv;
     (*shift)[i] = b->data[i] - mu->data[i] * inv;
   }
+  return DVSG_OK;
+}
+
+// (Re)make the stage-packed copies of a layer's PLAIN float16 weights (conv_gemm_wide16.hip; round 3 built the packing for
+// the stacked hi / lo rows only, so a layer without the lo piece fetched half-line weight rows again)
+int pack_plain(dvsg_locnet *net, ConvLayer *L) {
+  if (L->cin % 64 != 0 || L->cout % 128 != 0 || !L->wt16) return DVSG_OK;
+  auto pack = [&](int order, _Float16 **out) -> int {
+    if (!*out) {
+      void *pk = nullptr;
+      DVSG_HIP(hipMalloc(&pk, wide16_packed_bytes(L->cout, L->cin, L->ksize)));
+      net->allocs.push_back(pk);
+      *out = static_cast<_Float16 *>(pk);
+    }
+    return launch_pack_wide16(L->wt16, *out, L->cout, L->cin, L->ksize, order, nullptr);
+  };
+  if (int rc = pack(0, &L->wt16q)) return rc;
+  if (L->ksize == 1) {
+    L->wt16qa = L->wt16q;
+  } else {
+    if (int rc = pack(1, &L->wt16qa)) return rc;
+    if (int rc = pack(2, &L->wt16qh)) return rc;
+  }
+  DVSG_HIP(hipStreamSynchronize(nullptr));
   return DVSG_OK;
 }
 
@@ -185,6 +214,7 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
     }
     DVSG_HIP(hipStreamSynchronize(nullptr));
   }
+  if (int rc = pack_plain(net, L)) return rc;
   if (int rc = upload(net, wt32s, &L->wt32s)) return rc;
   return upload(net, shift, &L->bias);
 }
@@ -257,7 +287,9 @@ int g_f16_split = 1;
 // dvsg_debug_set_option("f16_pair_mask", m): A/B.
 int g_f16_pair_mask = 0xFFFF;
 enum LayerKind { kKindC1 = 0, kKindC2 = 1, kKindC3 = 2, kKindSc = 3 };
-inline bool f16_pairs(int block, int kind) { return g_f16_split && ((g_f16_pair_mask >> (4 * kind + block)) & 1); }
+inline bool f16_pairs(const dvsg_locnet *net, int block, int kind) {
+  return g_f16_split && ((g_f16_pair_mask & net->f16_pair_mask) >> (4 * kind + block)) & 1;
+}
 // block 1's shortcut conv inside the fused conv2 + conv3 kernel (dvsg_debug_set_option("fuse_shortcut", 0): A/B)
 int g_fuse_shortcut = 1;
 
@@ -328,12 +360,58 @@ int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int
     p.wt_packed = L.wt16p;
     p.wt_packed_a = L.wt16pa;
     p.wt_packed_h = L.wt16ph;
+  } else if (prec == kF16) {
+    p.wt_packed = L.wt16q;
+    p.wt_packed_a = L.wt16qa;
+    p.wt_packed_h = L.wt16qh;
   }
   p.B = B; p.H = H; p.W = W; p.Cin = L.cin; p.Ho = Ho; p.Wo = Wo; p.Cout = L.cout;
   p.ksize = L.ksize; p.stride = L.stride; p.pad = L.ksize == 3 ? 1 : 0;
   p.res_H = res_H; p.res_W = res_W; p.res_stride = res_stride;
   p.relu = relu;
   return launch_conv_gemm(p, s);
+}
+
+// ---- calibration of the float16 mode's PLAIN weights (dvsg_debug_calibrate_f16_weights) --------------------------------
+// While armed, forward() adds up every bottleneck unit's three convolution inputs per channel: slot 3 u + {0: the unit's
+// input (shortcut, conv1), 1: conv1's output (conv2's input), 2: conv2's output (conv3's input)}.
+struct Calib {
+  double *sums = nullptr;    // device [16 * 3][2048]
+  float *part = nullptr;     // device [kCalibBlocks][2048]: per-block partial sums of the tensor being recorded
+  double rows[48] = {0};     // pixels summed per slot
+  bool on = false;
+} g_calib;
+
+// deterministic: block b adds up rows [b chunk, (b + 1) chunk) per channel into part[b][c]; channel_sum_final adds the
+// blocks' partial sums in block order (double) onto out[c] -- the same bits from run to run, so the weights re-rounded from
+// them are the same bits too
+constexpr int kCalibBlocks = 512;
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float *__restrict__ x, long M, int C, long chunk,
+                                                         float *__restrict__ part) {
+  const long r0 = (long)blockIdx.x * chunk, r1 = r0 + chunk < M ? r0 + chunk : M;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += x[r * C + c];
+    part[(size_t)blockIdx.x * 2048 + c] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void channel_sum_final(const float *__restrict__ part, int nblk, int C, double *__restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double acc = out[c];
+  for (int b = 0; b < nblk; ++b) acc += (double)part[(size_t)b * 2048 + c];
+  out[c] = acc;
+}
+
+int calib_record(int slot, const void *x, long M, int C, hipStream_t s) {
+  if (!g_calib.on) return DVSG_OK;
+  const long chunk = (M + kCalibBlocks - 1) / kCalibBlocks;
+  const int nblk = (int)((M + chunk - 1) / chunk);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk), dim3(256), 0, s, static_cast<const float *>(x), M, C, chunk, g_calib.part);
+  hipLaunchKernelGGL(channel_sum_final, dim3((C + 255) / 256), dim3(256), 0, s, g_calib.part, nblk, C,
+                     g_calib.sums + (size_t)slot * 2048);
+  g_calib.rows[slot] += (double)M;
+  return check_launch("channel_sum_kernel");
 }
 
 // Runs the network in precision `prec`; stop_stage < 0 runs everything and writes F_t [B,50].
@@ -404,20 +482,22 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
     const int ho = (h - 1) / u.stride + 1, wo = (w - 1) / u.stride + 1;
     const void *res = X;
     int res_h = h, res_w = w, res_stride = u.stride;
+    const int calib_slot = 3 * (stage - 2);
+    DVSG_RUN(calib_record(calib_slot, X, (long)B * h * w, u.c1.cin, s));
     // (float16 mode: the fused kernel multiplies against the stacked hi / lo weights only)
     const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) &&
-                        (prec != kF16 || (f16_pairs(u.block, kKindC2) && f16_pairs(u.block, kKindC3) &&
-                                          (!u.has_shortcut || f16_pairs(u.block, kKindSc))));
+                        (prec != kF16 || (f16_pairs(net, u.block, kKindC2) && f16_pairs(net, u.block, kKindC3) &&
+                                          (!u.has_shortcut || f16_pairs(net, u.block, kKindSc))));
     // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
     const bool fuse_sc = fuse23 && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
                          g_fuse_shortcut;
     if (u.has_shortcut && !fuse_sc) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
-      DVSG_RUN(run_conv(prec, u.shortcut, f16_pairs(u.block, kKindSc), X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws,
+      DVSG_RUN(run_conv(prec, u.shortcut, f16_pairs(net, u.block, kKindSc), X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws,
                         &launch_idx, s));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
     }
-    DVSG_RUN(run_conv(prec, u.c1, f16_pairs(u.block, kKindC1), X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+    DVSG_RUN(run_conv(prec, u.c1, f16_pairs(net, u.block, kKindC1), X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
     if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
       const bool pcs = prec == kF32S;
@@ -437,9 +517,11 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       }
       DVSG_RUN(launch_conv3x3_1x1(f, s));
     } else {
-      DVSG_RUN(run_conv(prec, u.c2, f16_pairs(u.block, kKindC2), ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
+      DVSG_RUN(calib_record(calib_slot + 1, ws.r1, (long)B * h * w, u.c2.cin, s));
+      DVSG_RUN(run_conv(prec, u.c2, f16_pairs(net, u.block, kKindC2), ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
                         &launch_idx, s));
-      DVSG_RUN(run_conv(prec, u.c3, f16_pairs(u.block, kKindC3), ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true,
+      DVSG_RUN(calib_record(calib_slot + 2, ws.r2, (long)B * ho * wo, u.c3.cin, s));
+      DVSG_RUN(run_conv(prec, u.c3, f16_pairs(net, u.block, kKindC3), ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true,
                         ws, &launch_idx, s));
     }
     h = ho; w = wo;
@@ -555,21 +637,22 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
     // that may carry the packed weight copies below, which a slab user sizing itself by this field must never reach
     p.splitk_scratch_bytes = std::min(scratch_bytes - cbytes, align256(kSplitKSlabBytes));
   }
-  if (prec == kF16 && wsplit && Cin % 64 == 0 && Cout % 64 == 0 && (ksize == 1 || ksize == 3) && scratch) {
+  if (prec == kF16 && Cin % 64 == 0 && Cout % (wsplit ? 64 : 128) == 0 && (ksize == 1 || ksize == 3) && scratch) {
     // the packed weight copies conv_gemm_wide16.hip prefers (what dvsg_locnet_create makes once per layer), made here on
     // every call behind the tickets and the partial-tile slabs when the caller's scratch has room for them; without
     // them the layer runs from the [rows][K] layout
-    const size_t need = align256(wide16_packed_bytes(2 * Cout, Cin, ksize));
+    const int rows = wsplit ? 2 * Cout : Cout;   // stacked hi / lo rows, or plain ones
+    const size_t need = align256(wide16_packed_bytes(rows, Cin, ksize));
     const size_t base = cbytes + align256(kSplitKSlabBytes);
     if (scratch_bytes >= base + 3 * need) {
       char *pk = static_cast<char *>(scratch) + base;
-      if (int rc = launch_pack_wide16(wt, pk, 2 * Cout, Cin, ksize, 0, as_stream(stream))) return rc;
+      if (int rc = launch_pack_wide16(wt, pk, rows, Cin, ksize, 0, as_stream(stream))) return rc;
       p.wt_packed = pk;
       if (ksize == 1) {
         p.wt_packed_a = pk;
       } else {
-        if (int rc = launch_pack_wide16(wt, pk + need, 2 * Cout, Cin, ksize, 1, as_stream(stream))) return rc;
-        if (int rc = launch_pack_wide16(wt, pk + 2 * need, 2 * Cout, Cin, ksize, 2, as_stream(stream))) return rc;
+        if (int rc = launch_pack_wide16(wt, pk + need, rows, Cin, ksize, 1, as_stream(stream))) return rc;
+        if (int rc = launch_pack_wide16(wt, pk + 2 * need, rows, Cin, ksize, 2, as_stream(stream))) return rc;
         p.wt_packed_a = pk + need;
         p.wt_packed_h = pk + 2 * need;
       }
@@ -846,6 +929,112 @@ int dvsg_debug_set_option(const char *name, int value) {
     return DVSG_OK;
   }
   return fail(DVSG_ERR_INVALID_ARG, "dvsg_debug_set_option: unknown option %s", name);
+}
+
+// Error-feedback rounding of the float16 mode's PLAIN weights (the copies a layer without the lo piece multiplies by).
+// A float16 weight is off by up to 2^-12 relative, the same way at every pixel: through the mean activation mu_k of its
+// input channel that is a BIAS of its output channel, sum_k (q_k - w_k) mu_k, which the global average pool does not
+// average away -- 9/10 of the plain mode's F_t error, and what the hi / lo pairs exist to remove (at twice the MFMAs).
+// Here every weight is rounded to one of its two float16 neighbours so that the running sum of (q_k - w_k) mu_k along K
+// stays within half a step: the bias goes, the zero-mean part -- which the pool does average -- stays.  mu comes from ONE
+// float32 pass over `patches` (calibration windows) with block 1's fusion off, recorded per unit and convolution input.
+// mode 0: round to nearest again (undo); 1: mu = 1 (A/B: does nothing for F_t -- channel means are far from uniform);
+// 2: calibrated means.  Measured (tools/f16_ef_sweep.py, two 720p windows, synthetic checkpoint): plain weights 1.9e-5 ->
+// 2.7e-6 (hi / lo pairs everywhere: 1.6e-6), 22 % less time per step.
+static int calibrate_f16(dvsg_locnet *net, const float *patches, int B, int H, int W, int mode, void *workspace,
+                         size_t workspace_bytes, hipStream_t s) {
+  std::vector<double> mu((size_t)48 * 2048, 1.0);
+  if (mode == 2) {   // calibrated channel means
+    void *sums = nullptr, *part = nullptr, *F = nullptr;
+    hipError_t e = hipMalloc(&sums, 48 * 2048 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&part, (size_t)kCalibBlocks * 2048 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&F, (size_t)B * 50 * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(sums, 0, 48 * 2048 * sizeof(double), s);
+    int rc = e == hipSuccess ? DVSG_OK : fail(DVSG_ERR_HIP, "calibration: %s", hipGetErrorString(e));
+    if (rc == DVSG_OK) {
+      g_calib.sums = static_cast<double *>(sums);
+      g_calib.part = static_cast<float *>(part);
+      for (double &r : g_calib.rows) r = 0;
+      const int fuse_was = get_fuse_conv();
+      set_fuse_conv(0);       // block 1's conv2 output only exists in LDS when fused
+      g_calib.on = true;
+      rc = forward(net, kF32, patches, B, H, W, static_cast<float *>(F), -1, nullptr, 0, nullptr, workspace, workspace_bytes, s);
+      g_calib.on = false;
+      set_fuse_conv(fuse_was);
+      if (rc == DVSG_OK && hipMemcpyAsync(mu.data(), sums, mu.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
+        rc = fail(DVSG_ERR_HIP, "copy of the calibration sums failed");
+      if (rc == DVSG_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(DVSG_ERR_HIP, "calibration pass failed");
+    }
+    (void)hipFree(sums);
+    (void)hipFree(part);
+    (void)hipFree(F);
+    if (rc) return rc;
+    for (int slot = 0; slot < 48; ++slot)
+      for (int c = 0; c < 2048; ++c) mu[(size_t)slot * 2048 + c] = g_calib.rows[slot] > 0 ? mu[(size_t)slot * 2048 + c] / g_calib.rows[slot] : 1.0;
+  }
+  auto f16_bits = [](_Float16 v) { unsigned short b; std::memcpy(&b, &v, 2); return b; };
+  auto f16_from = [](unsigned short b) { _Float16 v; std::memcpy(&v, &b, 2); return v; };
+  auto neighbour = [&](_Float16 q, bool up) -> _Float16 {   // next float16 above / below q
+    unsigned short b = f16_bits(q);
+    if ((b & 0x7fff) == 0) return f16_from(up ? 0x0001 : 0x8001);
+    const bool neg = (b & 0x8000) != 0;
+    b = (unsigned short)((up != neg) ? b + 1 : b - 1);
+    return f16_from(b);
+  };
+  auto redo = [&](ConvLayer &L, const double *m) -> int {
+    const int K = L.ksize * L.ksize * L.cin;
+    std::vector<float> wt((size_t)L.cout * K);
+    DVSG_HIP(hipMemcpy(wt.data(), L.wt, wt.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<_Float16> q16(wt.size());
+    for (int n = 0; n < L.cout; ++n) {
+      double E = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const float w32 = wt[(size_t)n * K + k];
+        const _Float16 q0 = (_Float16)w32;
+        _Float16 q = q0;
+        if (mode != 0 && (float)q0 != w32) {
+          const _Float16 other = neighbour(q0, (float)q0 < w32);
+          const double mk = m[k % L.cin];                  // k = (kh, kw, c): the channel's mean for every tap
+          const double e0 = E + ((double)(float)q0 - w32) * mk, e1 = E + ((double)(float)other - w32) * mk;
+          const bool take = std::fabs(e1) < std::fabs(e0) && std::isfinite((float)other);
+          q = take ? other : q0;
+          E = take ? e1 : e0;
+        }
+        q16[(size_t)n * K + k] = q;
+      }
+    }
+    DVSG_HIP(hipMemcpy(L.wt16, q16.data(), q16.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    return pack_plain(net, &L);
+  };
+  int ui = 0;
+  for (Unit &u : net->units) {
+    const double *mx = mu.data() + (size_t)(3 * ui) * 2048;
+    if (u.has_shortcut) if (int rc = redo(u.shortcut, mx)) return rc;
+    if (int rc = redo(u.c1, mx)) return rc;
+    if (int rc = redo(u.c2, mx + 2048)) return rc;
+    if (int rc = redo(u.c3, mx + 2 * 2048)) return rc;
+    ++ui;
+  }
+  return DVSG_OK;
+}
+
+int dvsg_locnet_calibrate_f16(dvsg_locnet_t *net, const float *patches, int B, int H, int W, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(net && workspace, "dvsg_locnet_calibrate_f16: NULL pointer");
+  if (!patches) {   // undo: round-to-nearest plain copies, pairs everywhere
+    net->f16_pair_mask = 0xFFFF;
+    return calibrate_f16(net, nullptr, 0, 0, 0, 0, workspace, workspace_bytes, as_stream(stream));
+  }
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0, "dvsg_locnet_calibrate_f16: bad shape B=%d H=%d W=%d", B, H, W);
+  if (int rc = calibrate_f16(net, patches, B, H, W, 2, workspace, workspace_bytes, as_stream(stream))) return rc;
+  net->f16_pair_mask = 0x1111;   // block 1 (whose fused kernels multiply by the stacked pairs) keeps them; blocks 2-4 run plain
+  return DVSG_OK;
+}
+
+int dvsg_debug_calibrate_f16_weights(dvsg_locnet_t *net, const float *patches, int B, int H, int W, int mode, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(net && patches && workspace && mode >= 0 && mode <= 2, "dvsg_debug_calibrate_f16_weights: bad arguments");
+  return calibrate_f16(net, patches, B, H, W, mode, workspace, workspace_bytes, as_stream(stream));
 }
 
 int dvsg_stabilize_f32(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,

@@ -97,6 +97,14 @@ class StabNet:
     def load_ckpt(self, ckpt_dir, by_score=True):
         return self.load_weights(_weights.load_ckpt_dir(ckpt_dir, by_score))
 
+    def calibrate_f16(self, patches):
+        """Optional, for precision = "f16": `LocNet.calibrate_f16` on a few windows [B,H,W,3S] of the clip (no counterpart
+        in the reference, which has one precision)."""
+        if self.locnet is None:
+            raise _lib.DvsgError("StabNet has no weights: call load_weights()/load_ckpt() first")
+        self.locnet.calibrate_f16(patches)
+        return self
+
     def init_vars(self, sess=None, ckpt_path=None, weights=None):
         """model.py:125-154, callable as the reference calls it -- `net.init_vars(sess)` -- once the variables exist
         (`load_weights` / `load_ckpt` stand in for `tf.global_variables_initializer()`): every `resnet_v1_50/...`

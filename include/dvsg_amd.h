@@ -194,6 +194,20 @@ int dvsg_locnet_forward_tap_f16(const dvsg_locnet_t *net, const float *patches, 
 int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B,
                        int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* Calibration of the float16 mode (optional; round 4).  The hi / lo weight pairs cost twice the matrix-core work to remove
+ * ONE thing: the bias a rounded float16 weight leaves in its output channel through the MEAN of its input channel,
+ * sum_k (q_k - w_k) mu_k -- the same at every pixel, so the global average pool keeps it.  Given calibration windows
+ * `patches` [B,H,W,c_in] (a few frames of the clip about to be stabilised), this call measures mu per convolution input
+ * in one float32 pass and re-rounds the PLAIN float16 copy of every weight of blocks 2-4 to one of its two float16
+ * neighbours so that the running sum of (q_k - w_k) mu_k along K stays within half a step ("error feedback"); from then
+ * on the float16 entry points of this handle run blocks 2-4 on those plain weights (half the MFMAs) and keep the pairs in
+ * block 1.  Measured on MI355X (synthetic checkpoint, 720p, against a float64 CPU evaluation): F_t 2.0-2.6e-6 where the
+ * pairs give 1.4-1.9e-6 and round-to-nearest plain weights 1.9e-5; 22 % less time per step (tests/test_gpu_f16.py,
+ * tools/f16_ef_masks.py).  The means are those of the calibration windows: frames of other statistics bring part of the
+ * bias back (bounded by the plain mode's).  Deterministic (fixed-order sums); synchronous; mutates the handle, so not
+ * while another thread runs it.  patches == NULL restores the uncalibrated state (pairs everywhere). */
+int dvsg_locnet_calibrate_f16(dvsg_locnet_t *net, const float *patches, int B, int H, int W, void *workspace,
+                              size_t workspace_bytes, void *stream);
 /* ---------------------------------------------------------------------------------------
  * "f32s": float32 storage, float32 accumulation, float32-equivalent PRODUCTS from the float16 matrix
  * cores.  Same tensors, same workspace, same launch sequence as the *_f32 entry points (the dense head, the
@@ -362,6 +376,11 @@ int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, c
  * fused kernel; 0 selects the kernel each replaced), "warp_xcd" (0: the sampler kernels' workgroups in plain dispatch order).
  * Results do not depend on them beyond float32 re-association. */
 int dvsg_debug_set_option(const char *name, int value);
+/* The A/B form of dvsg_locnet_calibrate_f16 (tools/f16_ef_sweep.py): re-rounds the plain float16 weight copies and leaves
+ * the pair policy to "f16_pair_mask".  mode 0: round to nearest (what dvsg_locnet_create makes); 1: error feedback with
+ * mu = 1 (measured: useless -- channel means are far from uniform); 2: calibrated channel means. */
+int dvsg_debug_calibrate_f16_weights(dvsg_locnet_t *net, const float *patches, int B, int H, int W, int mode, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement hook (bench.py's roofline leg; not part of the reference surface).  While

@@ -58,6 +58,7 @@ def test_bench_default_line_carries_the_other_single_gpu_configs():
     assert c4["workload"].startswith("configs[4]") and c4["dtype"] == "f16" and c4["roofline"]["bound"] == "hbm"
     assert c4["value"] > 200 and abs(c4["value"] - 32 / (c4["ms_per_step"] * 1e-3)) / c4["value"] < 1e-6
     assert c4["roofline"]["launches"] == 32 * c4["steps"] and 0.2 < c4["roofline"]["frac"] < 1.0
+    assert c4["value"] > 1.1 * c4["pairs_everywhere"]["value"] > 250     # the calibrated mode is the faster one
 
 
 def test_bench_other_kernel_classes_and_precision():

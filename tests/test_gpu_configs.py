@@ -144,8 +144,11 @@ def test_cfg3_one_rank_shard_of_64_windows(dev, synthetic_weights):
         assert err[~mask].max() < 1e-3, "window %d: pixel error %.3g" % (b, err[~mask].max())
 
 
-def test_cfg4_b32_4k_f16(dev, synthetic_weights):
-    """configs[4]: B=32 3840x2160 windows in ONE `dvsg_stabilize_f16` call (22 GB of windows and a
+@pytest.mark.parametrize("calibrated", [False, True])
+def test_cfg4_b32_4k_f16(dev, synthetic_weights, calibrated):
+    """(calibrated: after `dvsg_locnet_calibrate_f16` on ONE other 3840x2160 window -- blocks 2-4 on error-feedback-rounded
+    plain float16 weights, 22 % less time -- the same bounds hold.)
+    configs[4]: B=32 3840x2160 windows in ONE `dvsg_stabilize_f16` call (22 GB of windows and a
     ~60 GB workspace fit the 288 GB of HBM: no sub-batching).  float16 storage cannot be bit-compatible
     with the float32 reference; stated bound against the float32 CPU oracle at this size:
     F_t < 1e-5 (|F_t| ~ 0.1; float16 activations, hi / lo float16 weight pairs -- tests/test_gpu_f16.py).  Exact properties: bitwise run-to-run determinism, batch invariance up to
@@ -155,6 +158,8 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
     from coupe.dvsg_amd.networks import LocNet
     B, H, W = 32, 2160, 3840
     net = LocNet(synthetic_weights)
+    if calibrated:
+        net.calibrate_f16(_gpu_windows(1, H, W, 499, dev))
     x = torch.cat([_gpu_windows(8, H, W, 400 + i, dev) for i in range(4)], 0)
     u = x[..., 18:].contiguous()
     out = torch.empty((B, H, W, 3), device=dev)
@@ -200,9 +205,9 @@ def test_cfg4_b32_4k_f16(dev, synthetic_weights):
         f64 = otps.interpolate_a_f64(u21, xb, yb)[0].reshape(len(rows), W, 3)
         e64[rows] = np.abs(got21[rows] - f64).max(axis=2)
         o64[rows] = np.abs(rpred[0][rows] - f64).max(axis=2)
-    print("cfg4 window 21: F_t error %.3g; pixels vs float32 oracle max %.3g median %.3g; vs float64 arbiter: GPU %.3g, "
+    print("cfg4 (calibrated: %s) window 21: F_t error %.3g; pixels vs float32 oracle max %.3g median %.3g; vs float64 arbiter: GPU %.3g, "
           "float32 oracle %.3g (outside %d border pixels)"
-          % (err, perr[~mask].max(), np.median(perr), e64[~mask].max(), o64[~mask].max(), int(mask.sum())))
+          % (calibrated, err, perr[~mask].max(), np.median(perr), e64[~mask].max(), o64[~mask].max(), int(mask.sum())))
     # measured: F_t 9.6e-7; pixels 9.0e-4 max / 9.0e-5 median against the float32 oracle (round 3: 9.6e-4) -- but 3.9e-4
     # against the float64 arbiter, from which the float32 ORACLE is 9.0e-4 away: the zero margin of round 3 was the
     # oracle's own float32 noise at W = 3840, not the float16 mode's error (476 border pixels)

@@ -286,6 +286,58 @@ def test_wide_f16_tiles_match_float32_math_and_the_128_tiles():
         _lib.call("dvsg_debug_set_option", b"wide16_hreuse", 1)
 
 
+def test_calibrated_float16_mode(synthetic_weights):
+    """dvsg_locnet_calibrate_f16: plain float16 weights in blocks 2-4, re-rounded with error feedback against the mean
+    activation of their input channels (measured on OTHER frames than the ones tested: two 288x512 windows).  F_t at 720p
+    against a float64 CPU evaluation of the graph: < 3e-6 (measured 2.0-2.6e-6; hi / lo pairs everywhere 1.4-1.9e-6,
+    round-to-nearest plain weights 1.9e-5), the pixel tolerance of BASELINE.json still met, deterministic across two
+    calibrations, and undone by calibrate_f16(None)."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    from coupe.dvsg_amd.networks import LocNet
+    from oracle import model as omodel
+    from oracle.cnn_torch import TorchLocNet
+    from oracle.thin_plate_spline import ThinPlateSpline as ostn
+    from oracle.thin_plate_spline import border_discontinuity_mask
+    H, W = 720, 1280
+    net = LocNet(synthetic_weights)
+    oracle = TorchLocNet(synthetic_weights, dtype=torch.float64)
+    calib = inputs.window_frames(991, 2, 288, 512)
+    tests = [inputs.window_frames(seed, 1, H, W) for seed in (7, 77)]
+    refs = [oracle.forward(x) for x in tests]
+    xs = [torch.from_numpy(x).cuda() for x in tests]
+    paired = [net.forward(x, precision="f16") for x in xs]
+    e_pairs = max(np.abs(F.cpu().numpy() - r).max() for F, r in zip(paired, refs))
+    net.calibrate_f16(calib)
+    cal = [net.forward(x, precision="f16") for x in xs]
+    e_cal = max(np.abs(F.cpu().numpy() - r).max() for F, r in zip(cal, refs))
+    # what the calibration replaces: the same layers on round-to-nearest plain weights
+    ws, nbytes = net.workspace(2, 288, 512)
+    cd = torch.from_numpy(calib).cuda()
+    _lib.call("dvsg_debug_calibrate_f16_weights", net.handle, cd.data_ptr(), 2, 288, 512, 0, ws.data_ptr(), nbytes,
+              torch.cuda.current_stream().cuda_stream)
+    e_rtn = max(np.abs(net.forward(x, precision="f16").cpu().numpy() - r).max() for x, r in zip(xs, refs))
+    net.calibrate_f16(calib)
+    again = [net.forward(x, precision="f16") for x in xs]
+    print("float16 mode F_t error at 720p vs float64: pairs %.2e, calibrated plain (blocks 2-4) %.2e, round-to-nearest plain %.2e"
+          % (e_pairs, e_cal, e_rtn))
+    assert e_pairs < 2.5e-6 and e_cal < 3e-6 and e_rtn > 3 * e_cal
+    assert all(torch.equal(a, b) for a, b in zip(cal, again))                 # the calibration itself is deterministic
+    # end to end in pixels (one window): the warp on the calibrated F_t against the float64 F_t's frame
+    x = tests[0]
+    out = torch.empty((1, H, W, 3), device="cuda")
+    F = torch.empty((1, 25, 2), device="cuda")
+    net.stabilize(xs[0], xs[0][..., 18:].contiguous(), out, F, precision="f16")
+    rpred, rx, ry = ostn(x[..., 18:], np.tile(omodel.v_src()[None], (1, 1, 1)), refs[0].astype(np.float32), (H, W))
+    border = border_discontinuity_mask(rx, ry, H, W, delta=3e-2).reshape(1, H, W)
+    perr = np.abs(out.cpu().numpy() - rpred).max(axis=3)[~border].max()
+    assert perr < 1e-3, perr
+    net.calibrate_f16(None)
+    assert all(torch.equal(net.forward(x, precision="f16"), p) for x, p in zip(xs, paired))   # undone: the paired mode's bits
+    # the float32 path never sees any of it
+    assert np.abs(net.forward(xs[0], precision="f32").cpu().numpy() - refs[0]).max() <= 1e-5
+
+
 def test_plain_float16_layers_on_the_wide_tiles():
     """A layer WITHOUT the lo piece (`dvsg_conv_gemm_f16`; in the network: `f16_split=0` or a layer cleared in
     `f16_pair_mask`) with Cout % 128 == 0 and Cin % 64 == 0 runs, from `wide16_min_tiles` tiles on, in the SPLIT = false
@@ -297,6 +349,7 @@ def test_plain_float16_layers_on_the_wide_tiles():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(15)
     st = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(160 << 20, dtype=torch.uint8, device=dev)   # tickets + slabs + room for the packed weight copies
     cases = [  # k, stride, cin, cout, B, h, w, residual mode (0 none, 1 same shape, 2 subsampled input-sized), relu
         (3, 2, 128, 128, 2, 23, 31, 0, 1), (1, 1, 256, 128, 5, 9, 13, 1, 0), (1, 1, 64, 256, 2, 37, 41, 2, 1),
         (3, 1, 256, 256, 1, 16, 16, 1, 1), (3, 1, 64, 128, 2, 1, 300, 0, 0), (3, 1, 128, 128, 1, 127, 4, 1, 1),
@@ -320,13 +373,18 @@ def test_plain_float16_layers_on_the_wide_tiles():
             else:
                 res, res_at = None, None
             outs = {}
-            for key, variant, thr, arows in (("wide", 0, 1, 1), ("wide_rows64", 0, 1, 0), ("t128", 5, 128, 1)):
+            # plain weights from their [Cout][K] layout (no scratch), from the stage-packed copies the network keeps (scratch
+            # given: 128-byte activation rows / a 3x3 kernel row's taps from one staged run where they apply, forced for
+            # every K with arows = 2), and on the 128 x 128 kernel
+            for key, variant, thr, arows, scr in (("wide", 0, 1, 1, 0), ("wide_rows64", 0, 1, 0, 0), ("packed", 0, 1, 2, 1),
+                                                  ("packed_rows64", 0, 1, 0, 1), ("t128", 5, 128, 1, 0)):
                 _lib.call("dvsg_debug_set_option", b"conv_variant", variant)
                 _lib.call("dvsg_debug_set_option", b"wide16_min_tiles", thr)
                 _lib.call("dvsg_debug_set_option", b"wide16_arows", arows)
                 y = torch.full((B, ho, wo, cout), float("nan"), device=dev, dtype=torch.float16)
                 _lib.call("dvsg_conv_gemm_f16", x.data_ptr(), w16.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else 0,
-                          y.data_ptr(), B, h, w, cin, cout, k, stride, relu, res_stride, 0, 0, st)
+                          y.data_ptr(), B, h, w, cin, cout, k, stride, relu, res_stride, scratch.data_ptr() if scr else 0,
+                          scratch.numel() if scr else 0, st)
                 outs[key] = y.float()
             w4 = w16.float().reshape(cout, k, k, cin).permute(0, 3, 1, 2)
             ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w4, bias, stride=stride, padding=k // 2).permute(0, 2, 3, 1)
@@ -336,7 +394,11 @@ def test_plain_float16_layers_on_the_wide_tiles():
                 ref = torch.relu(ref)
             scale = max(1.0, float(ref.abs().max()))
             case = (k, stride, cin, cout, B, h, w, rmode, relu)
-            for key in ("wide", "wide_rows64", "t128"):
+            if k == 1 or stride == 2:    # packing moves bytes, not sums (a 3x3 stride-1 layer with packed copies takes the kernel
+                assert torch.equal(outs["packed_rows64"], outs["wide_rows64"]), case   # that visits K in another order)
+            else:
+                assert float((outs["packed_rows64"] - outs["wide_rows64"]).abs().max()) < 1.0e-3 * scale, case
+            for key in ("wide", "wide_rows64", "packed", "packed_rows64", "t128"):
                 assert bool(torch.isfinite(outs[key]).all()), (key, case)
                 assert float((outs[key] - ref).abs().max()) < 1.2e-3 * scale, (key, case)     # float16 rounding of the output
             assert float((outs["wide"] - outs["t128"]).abs().max()) < 1.0e-3 * scale, case   # one float16 ulp of the output
