@@ -3,8 +3,10 @@
 The fixed-shape tests pin the cases someone thought of; this one draws (B, H, W) from a seeded generator -- biased towards
 the edges of the kernels' tilings (128-pixel conv1 column tiles, 4-row quads, the 16-byte row grid, one-pixel frames) --
 and checks, per shape and precision: F_t against the torch-CPU oracle, the source grid and the warped frame against the
-NumPy oracle (models/thin_plate_spline.py restated), and the frame-ring entry points (float32 and uint8 pools) against
-the gathered window BIT for bit.  DVSG_FUZZ_N raises the number of shapes (default 24, ~1 min); DVSG_FUZZ_SEED moves
+NumPy oracle (models/thin_plate_spline.py restated), the frame-ring entry points (float32 and uint8 pools) against
+the gathered window BIT for bit, eval_train.py's MASKED graph (the mask plane fused into conv1's staging: window, float ring
+and uint8 ring agree bit for bit, F_t against the oracle on `patches * mask`), and tf_warp's strip kernel against its gather
+kernel bit for bit.  DVSG_FUZZ_N raises the number of shapes (default 24, ~1 min); DVSG_FUZZ_SEED moves
 the draw.  A failure prints the shape: add it to the fixed lists of test_gpu_cnn.py / test_gpu_ring.py with the fix."""
 import os
 
@@ -87,3 +89,31 @@ def test_random_shape_against_the_oracle_and_the_ring(net, synthetic_weights, B,
         net.stabilize(x8, x8[..., 18:].contiguous(), out, F, precision=prec)
         net.stabilize_ring(pool8, table, out_r, F_r, precision=prec)
         assert torch.equal(F_r, F) and torch.equal(out_r, out), "%s uint8 ring differs at B=%d H=%d W=%d" % (prec, B, H, W)
+        # eval_train.py's masked graph: the three sources agree bit for bit; F_t against the oracle on patches * mask
+        from coupe.dvsg_amd.networks import random_mask_plane
+        plane = random_mask_plane(inputs.mask_homographies(17 * H + W, B) * np.float32(1.0), H, W)
+        net.stabilize(x8, x8[..., 18:].contiguous(), out, F, precision=prec, mask=plane)
+        net.stabilize_ring(pool8, table, out_r, F_r, precision=prec, mask=plane)
+        assert torch.equal(F_r, F) and torch.equal(out_r, out), "%s masked uint8 ring differs at B=%d H=%d W=%d" % (prec, B, H, W)
+        net.stabilize(x, u, out, F, precision=prec, mask=plane)
+        net.stabilize_ring(pool, table, out_r, F_r, precision=prec, mask=plane)
+        assert torch.equal(F_r, F) and torch.equal(out_r, out), "%s masked float ring differs at B=%d H=%d W=%d" % (prec, B, H, W)
+        if prec == "f32":
+            xm = x_np.copy()
+            xm[..., :18] *= plane.cpu().numpy()[..., None]
+            ferr = np.abs(F.cpu().numpy() - TorchLocNet(synthetic_weights).forward(xm)).max()
+            assert ferr <= 1e-5, "masked F_t error %.3g at B=%d H=%d W=%d" % (ferr, B, H, W)
+    # tf_warp: the strip kernel (LDS-staged source rows) gives the gather kernel's bits on a flow that leaves the window in places
+    from coupe.dvsg_amd import _lib
+    rng = np.random.default_rng(H * 7 + W)
+    flow = torch.from_numpy((8.0 * rng.standard_normal((B, H, W, 2))).astype(np.float32)).cuda()
+    got = {}
+    try:
+        for v in (0, 1):
+            _lib.call("dvsg_debug_set_option", b"flow_tiled", v)
+            o = torch.full((B, H, W, 3), float("nan"), device="cuda")
+            _lib.call("dvsg_flow_warp_f32", u.data_ptr(), flow.data_ptr(), B, H, W, 3, o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            got[v] = o
+    finally:
+        _lib.call("dvsg_debug_set_option", b"flow_tiled", 1)
+    assert torch.equal(got[0], got[1]), "tf_warp strip kernel differs at B=%d H=%d W=%d" % (B, H, W)
