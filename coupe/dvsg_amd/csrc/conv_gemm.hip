@@ -638,7 +638,10 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
   // Fat 4-wave workgroups when a single (partial) round of tiles covers the launch, else 8 waves
   // (4 per SIMD at 2 workgroups per CU): short K loops are prologue / epilogue bound and want more
   // waves in flight.  (A 4-stage LDS-DMA ring, 96 KB of LDS and one workgroup per CU, was measured
-  // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.)
+  // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.  Round 4 measured it again where that
+  // argument does not apply -- the split-K launches of batch 1-2, at most one workgroup per CU, three stages in flight
+  // behind counted waits and a barrier that leaves them in flight, same bits: 1.120 against 1.086 ms per 512x288 frame,
+  // 2.214 against 2.110 ms at 720p, profiles/r04_latency_ab_ring4_rejected.log.  A slice's stages do not wait for memory.)
   // f32s (SPLIT, float): a tile's matrix-core time is a fifth of the exact path's, so the 4 fat waves win at every
   // tile count -- half the fragment reads per MFMA -- (measured per layer, tools/conv_bench.py --precision f32s)
   const bool four = g_conv_variant == 1 || (SPLIT && sizeof(T) == 4 && g_conv_variant == 0) ||
