@@ -641,7 +641,11 @@ int launch_ks(ConvGemmDev d, bool wide, int streamk_tail, bool relu, int res, hi
   // for the small launches and lost 3-10 % to two 2-stage workgroups per CU.  Round 4 measured it again where that
   // argument does not apply -- the split-K launches of batch 1-2, at most one workgroup per CU, three stages in flight
   // behind counted waits and a barrier that leaves them in flight, same bits: 1.120 against 1.086 ms per 512x288 frame,
-  // 2.214 against 2.110 ms at 720p, profiles/r04_latency_ab_ring4_rejected.log.  A slice's stages do not wait for memory.)
+  // 2.214 against 2.110 ms at 720p, profiles/r04_latency_ab_ring4_rejected.log.  A slice's stages do not wait for memory.
+  // Nor is the slice's MFMA chain what a split-K launch costs: 8 waves of 32 x 32 per workgroup instead of 4 of 64 x 32 --
+  // half the matrix-core work per wave, twice the waves -- 1.074 against 1.089 ms at 512x288, 2.111 = 2.112 at 720p,
+  // +0.5 % at batch 2 (profiles/r04_latency_ab_8waves.log).  What is left per launch is fixed: ramp, prologue, first
+  // round trip, transpose, partial-tile exchange, drain -- 13-25 us where an empty kernel takes 5.)
   // f32s (SPLIT, float): a tile's matrix-core time is a fifth of the exact path's, so the 4 fat waves win at every
   // tile count -- half the fragment reads per MFMA -- (measured per layer, tools/conv_bench.py --precision f32s)
   const bool four = g_conv_variant == 1 || (SPLIT && sizeof(T) == 4 && g_conv_variant == 0) ||
