@@ -673,22 +673,25 @@ __global__ __launch_bounds__(kThreads) void mask_plane_kernel(const float *__res
 // taps and then stage it -- gave the same bits 25 % SLOWER: flow load -> reduction -> window load -> gather is three
 // dependent memory round trips per tile with 12 waves per CU, and the box of a 64 x 16 tile under this flow is 3.2 tiles.)
 //
-// Here a workgroup owns a strip of 128 output columns and marches down a band of rows, 8 at a time.  The source window
+// Here a workgroup owns a strip of 128 output columns and marches down a band of rows, 16 at a time.  The source window
 // is FIXED relative to the step -- the step's rows and columns +- 12 pixels -- so nothing about it depends on the flow:
-// its rows stream through a ring of 41 LDS rows, each fetched once per strip as whole 16-byte chunks per lane (1 KB per
-// wave instruction), the 8 new rows and the flow of step s + 1 requested before step s is computed.  Taps inside the
+// its rows stream through a ring of 57 LDS rows (106 KB, one workgroup of 16 waves per CU), each fetched once per strip
+// as whole 16-byte chunks per lane (1 KB per wave instruction), the 16 new rows and the flow of step s + 2 requested
+// before step s is computed.  Taps inside the
 // window come from LDS; a pixel with a tap outside it (a flow beyond +- 12 px: 0.3 % of the pixels at sigma = 4) takes
 // its four taps from global memory as before; taps on the zero ring are never read.  Geometry (`padded_geom`) and blend
 // are the functions stn_kernel uses on the same values in the same order: the output is bit-identical.
 // ----------------------------------------------------------------------------------------
-constexpr int kFsThreads = 512;                            // 8 waves: 128 columns x 4 row pairs
-constexpr int kFsW = 128, kFsStep = 8, kFsPPT = 2;         // strip width, rows per step, rows per thread
+constexpr int kFsThreads = 1024;                           // 8 waves: 128 columns x 4 row pairs
+constexpr int kFsW = 128, kFsStep = 16, kFsPPT = 2;        // strip width, rows per step, rows per thread
 constexpr int kFsMX = 12, kFsMY = 12;                     // window margins, pixels
 constexpr int kFsCols = kFsW + 2 * kFsMX + 1;             // 153 pixels: taps x .. x + 1
 constexpr int kFsCpr = (kFsCols * 12 + 12 + 15) / 16;     // 116 chunks of 16 bytes per window row (up to 12 bytes of lead-in)
-constexpr int kFsLive = kFsStep + 2 * kFsMY + 1;          // 33 rows feed a step
-constexpr int kFsRing = kFsLive + kFsStep;                // 41: the next step's 8 new rows land beside them
+constexpr int kFsLive = kFsStep + 2 * kFsMY + 1;          // 41 rows feed a step
+constexpr int kFsRing = kFsLive + kFsStep;                // 57: the next step's 16 new rows land beside them
 constexpr int kFsNew = (kFsStep * kFsCpr + kFsThreads - 1) / kFsThreads;   // 2 chunks per thread and step
+// (steps of 8 rows with 512 threads and two workgroups per CU -- the same 16 waves -- were 3 % slower: twice the barriers;
+// steps of 24 rows, 135 KB, three rows per thread: 530 us against 390)
 
 struct FlowStripParams {
   const float *im;      // [B,H,W,3], 16-byte aligned
@@ -705,7 +708,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __global__ __launch_bounds__(kFsThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void flow_warp_strip_kernel(FlowStripParams p) {
-  __shared__ __attribute__((aligned(16))) float ring[kFsRing * kFsCpr * 4];   // 76 KB: two workgroups (32 waves) per CU
+  __shared__ __attribute__((aligned(16))) float ring[kFsRing * kFsCpr * 4];   // 106 KB: one workgroup (16 waves) per CU
   const int t = threadIdx.x;
   const int id = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int strip = id % p.nstrips, band = (id / p.nstrips) % p.nbands, b = id / (p.nstrips * p.nbands);
@@ -1052,9 +1055,9 @@ int dvsg_flow_warp_f32(const float *im, const float *flow, int B, int H, int W, 
     q.im = im; q.flow = flow; q.out = out;
     q.H = H; q.W = W; q.B = B;
     q.nstrips = ceil_div(W, kFsW);
-    // bands: enough workgroups for >= 4 rounds of the 512 resident ones, bands of >= 64 rows (a band primes 33 rows)
+    // bands: enough workgroups for >= 4 rounds of the 256 resident ones, bands of >= 128 rows (a band primes 41 rows)
     const int steps = ceil_div(H, kFsStep);
-    int bands = (int)std::min<long>(std::max<long>(1, ((long)g_flow_rounds * 512 + (long)q.nstrips * B - 1) / ((long)q.nstrips * B)), std::max(1, steps / 8));
+    int bands = (int)std::min<long>(std::max<long>(1, ((long)g_flow_rounds * 256 + (long)q.nstrips * B - 1) / ((long)q.nstrips * B)), std::max(1, steps / 8));
     const int band_steps = ceil_div(steps, bands);
     q.band_rows = band_steps * kFsStep;
     q.nbands = ceil_div(H, q.band_rows);
