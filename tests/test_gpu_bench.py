@@ -37,10 +37,11 @@ def test_bench_line_has_the_contract_fields():
     s2 = d["secondary"]      # the f32s rate, beside the line of record and outside its timed region
     assert s2["precision"] == "f32s" and s2["dtype"] == "f32x2f16" and s2["value"] > 0
     # the reference's own operating point -- eval.py's batch-1 autoregressive clip loop -- beside the line, with a bound
-    # that catches a regression of the per-frame path (measured on MI355X, round 3: 2.14 ms at 720p, 1.11 ms at 512x288)
+    # that catches a regression of the per-frame path: 1.25 x the measured values (MI355X, rounds 3 and 4: 2.14-2.15 ms at
+    # 720p, 1.10-1.11 ms at 512x288)
     lat = d["latency"]
     assert "error" not in lat, lat
-    assert 0 < lat["1280x720"]["ms_per_frame"] < 3.0 and 0 < lat["512x288"]["ms_per_frame"] < 1.6
+    assert 0 < lat["1280x720"]["ms_per_frame"] < 2.7 and 0 < lat["512x288"]["ms_per_frame"] < 1.39
     assert abs(lat["1280x720"]["achieved_tflops"] - 154.5 / lat["1280x720"]["ms_per_frame"]) < 1e-6
 
 
