@@ -111,7 +111,8 @@ def load():
                      ("DVSG_F16_SPLIT", b"f16_split"), ("DVSG_FUSE_SHORTCUT", b"fuse_shortcut"),
                      ("DVSG_CONV1_VARIANT", b"conv1_variant"), ("DVSG_F16_PAIR_MASK", b"f16_pair_mask"),
                      ("DVSG_WIDE16_PACKED", b"wide16_packed"), ("DVSG_WIDE16_AROWS", b"wide16_arows"),
-                     ("DVSG_WIDE16_HREUSE", b"wide16_hreuse"), ("DVSG_FUSED_HREUSE", b"fused_hreuse")):
+                     ("DVSG_WIDE16_HREUSE", b"wide16_hreuse"), ("DVSG_FUSED_HREUSE", b"fused_hreuse"),
+                     ("DVSG_CONCAT_SC", b"concat_sc"), ("DVSG_FLOW_TILED", b"flow_tiled")):
         if os.environ.get(env) and os.environ.get("DVSG_DEBUG") == "1":
             check(lib.dvsg_debug_set_option(opt, int(os.environ[env])), "dvsg_debug_set_option")
     return lib

@@ -35,6 +35,10 @@ struct ConvGemm {
   int ksize, stride, pad;
   int res_H, res_W, res_stride;
   int relu;
+  // float32 / f32s only (0 / -1 = the dense defaults): x and res may be column ranges of wider tensors -- ldx, res_ld elements
+  // between two pixels -- and, with relu == 0, output channels >= relu_from get the ReLU all the same: a unit's `shortcut`
+  // (no ReLU) and `conv1` (ReLU) read the same input and run as ONE launch over their concatenated weight rows (locnet.hip)
+  int ldx = 0, res_ld = 0, relu_from = -1;
   const void *wt_packed = nullptr;   // kF16, optional: the rows of `wt` packed stage by stage for conv_gemm_wide16.hip (launch_pack_wide16, order 0)
   const void *wt_packed_a = nullptr; // ... in order 1, for its 128-byte-activation-row kernel
   const void *wt_packed_h = nullptr; // ... in order 2, for its 3x3 stride-1 kernel (a kernel row's taps from one staged run)

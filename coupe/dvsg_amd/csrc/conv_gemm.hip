@@ -101,6 +101,9 @@ struct ConvGemmDev {
   int res_H, res_W, res_stride;
   int M, K, mtiles, ntiles;
   int mt_fast;     // tile order, see run_segment
+  int ldx;         // elements between two pixels of x (Cin, or more when x is a column range of a wider tensor)
+  int res_ld;      // the same for the residual (Cout by default)
+  int relu_from;   // RELU = false instantiations: output channels >= relu_from get the ReLU all the same (INT_MAX: none)
 };
 
 // SPLIT, T = _Float16 ("f16" precision): the weight matrix holds, for every group of 64 output channels,
@@ -204,7 +207,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       const int m = m0 + row;
       const int mm = m < p.M ? m : 0;
       if (dense) {
-        a_off[i] = (long)mm * p.Cin + CHE * chunk;
+        a_off[i] = (long)mm * p.ldx + CHE * chunk;
         a_mask[i] = m < p.M ? 0x11u : 0u;
         continue;
       }
@@ -213,7 +216,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       const int ho = t % p.Ho;
       const int b = t / p.Ho;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + CHE * chunk;
+      a_off[i] = (((long)b * p.H + hi0) * p.W + wi0) * p.ldx + CHE * chunk;
       unsigned mk = 0;
       if (m < p.M) {
 #pragma unroll
@@ -244,7 +247,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
       s_kw = tap - s_kh * KS;
     }
     auto issue_stage = [&](int buf) __attribute__((always_inline)) {
-      const T *xa = px + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
+      const T *xa = px + ((long)s_kh * p.W + s_kw) * p.ldx + s_c0;
       const int wk = KS > 1 ? (s_kh * KS + s_kw) * p.Cin + s_c0 : s_c0;
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
@@ -356,13 +359,13 @@ void conv_gemm_kernel(ConvGemmDev p) {
         const int m = mr < p.M ? mr : p.M - 1;
         size_t roff;
         if (RES == 1) {
-          roff = (size_t)m * p.Cout + n;
+          roff = (size_t)m * p.res_ld + n;
         } else {  // slim `subsample`: shortcut = x[:, ::s, ::s, :]
           const int wo = m % p.Wo;
           const int t = m / p.Wo;
           const int ho = t % p.Ho;
           const int b = t / p.Ho;
-          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+          roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.res_ld + n;
         }
         rv[i] = PSPLIT ? load4_p_pair(p.res, roff, col4 & 1) : load4(pres + roff);
       }
@@ -499,13 +502,13 @@ void conv_gemm_kernel(ConvGemmDev p) {
         if (reduce) {  // the finishing contributor of a split tile loads it here
           size_t roff;
           if (RES == 1) {
-            roff = (size_t)m * p.Cout + n;
+            roff = (size_t)m * p.res_ld + n;
           } else {
             const int wo = m % p.Wo;
             const int t = m / p.Wo;
             const int ho = t % p.Ho;
             const int b = t / p.Ho;
-            roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.Cout + n;
+            roff = (((size_t)b * p.res_H + (size_t)ho * p.res_stride) * p.res_W + (size_t)wo * p.res_stride) * p.res_ld + n;
           }
           r4 = PSPLIT ? load4_p_pair(p.res, roff, col4 & 1) : load4(pres + roff);
         } else {
@@ -513,7 +516,7 @@ void conv_gemm_kernel(ConvGemmDev p) {
         }
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
       }
-      if (RELU) {
+      if (RELU || n >= p.relu_from) {   // (the thread's four channels sit on one side of relu_from: it is a multiple of 64)
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
       if (PSPLIT) store4_p_pair(p.y, (size_t)m * p.Cout + n, v, col4 & 1, true);  // lanes 2j, 2j+1: one pixel, 8 channels
@@ -689,6 +692,13 @@ int launch_conv_gemm(const ConvGemm &p, hipStream_t s) {
   d.H = p.H; d.W = p.W; d.Cin = p.Cin; d.Ho = p.Ho; d.Wo = p.Wo; d.Cout = p.Cout;
   d.stride = p.stride; d.pad = p.pad;
   d.res_H = p.res_H; d.res_W = p.res_W; d.res_stride = p.res_stride;
+  d.ldx = p.ldx > 0 ? p.ldx : p.Cin;
+  d.res_ld = p.res_ld > 0 ? p.res_ld : p.Cout;
+  d.relu_from = p.relu_from >= 0 ? p.relu_from : 0x7fffffff;
+  DVSG_REQUIRE(p.prec != kF16 || (d.ldx == p.Cin && d.res_ld == p.Cout && p.relu_from < 0),
+               "conv_gemm: row strides / a partial ReLU are the float32 kernels' only");
+  DVSG_REQUIRE(d.ldx >= p.Cin && d.ldx % bke == 0 && d.res_ld >= p.Cout && d.res_ld % 4 == 0 && (p.relu_from < 0 || (p.relu_from % 64 == 0 && !p.relu)),
+               "conv_gemm: bad strides ldx=%d res_ld=%d relu_from=%d", d.ldx, d.res_ld, p.relu_from);
   d.M = (int)M;
   d.K = p.ksize * p.ksize * p.Cin;
   d.mtiles = (int)((M + BM - 1) / BM);

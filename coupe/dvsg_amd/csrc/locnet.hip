@@ -51,6 +51,10 @@ struct Unit {
   int base, depth, stride;
   bool has_shortcut;
   ConvLayer shortcut, c1, c2, c3;
+  // units that open blocks 2-4: `shortcut` and `conv1` read the same input -- their weight rows concatenated along N
+  // ([shortcut | conv1], float32 and f32s pieces) run as ONE launch (forward(), "concat_sc")
+  ConvLayer cat;
+  bool has_cat = false;
 };
 
 struct BlockSpec {
@@ -292,6 +296,8 @@ inline bool f16_pairs(const dvsg_locnet *net, int block, int kind) {
 }
 // block 1's shortcut conv inside the fused conv2 + conv3 kernel (dvsg_debug_set_option("fuse_shortcut", 0): A/B)
 int g_fuse_shortcut = 1;
+// blocks 2-4's opening units: shortcut + conv1 as one launch (dvsg_debug_set_option("concat_sc", 0): A/B)
+int g_concat_sc = 1;
 
 struct Workspace {
   char *bufA, *bufB, *bufS, *r1, *r2;  // activations (element type = the run's precision)
@@ -318,6 +324,7 @@ Workspace plan(char *base, int B, int H, int W) {
         const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
         small_el = std::max(small_el, (size_t)h * w * bs.base);                  // r1 (conv1 out), r2 <= r1
         big_el = std::max(big_el, (size_t)ho * wo * bs.base * 4);                // unit out, shortcut
+        if (u == 1) big_el = std::max(big_el, (size_t)h * w * bs.base * 5);     // [shortcut | conv1] of an opening unit (bufS)
         h = ho; w = wo;
       }
   }
@@ -348,8 +355,9 @@ Workspace plan(char *base, int B, int H, int W) {
 
 int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int H, int W, void *y, int Ho, int Wo,
              const void *res, int res_H, int res_W, int res_stride, bool relu, const Workspace &ws, int *launch_idx,
-             hipStream_t s) {
+             hipStream_t s, int ldx = 0, int res_ld = 0, int relu_from = -1) {
   ConvGemm p;
+  p.ldx = ldx; p.res_ld = res_ld; p.relu_from = relu_from;
   p.splitk_scratch = ws.splitk_slabs;
   p.splitk_scratch_bytes = kSplitKSlabBytes;
   p.splitk_counters = ws.splitk_counters + (size_t)((*launch_idx)++ % kMaxConvLaunches) * kSplitKMaxTiles;
@@ -491,6 +499,21 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
     // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
     const bool fuse_sc = fuse23 && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
                          g_fuse_shortcut;
+    // blocks 2-4's opening units, float32 / f32s: shortcut and conv1 as ONE launch over [shortcut | conv1] weight rows; its
+    // output [M, depth + base] sits in bufS, the shortcut in columns [0, depth) (conv3's residual, row stride depth + base),
+    // conv1's ReLU'd output behind it (conv2's input, same stride).  One launch and one read of the unit's input less.
+    const bool cat = u.has_shortcut && !fuse_sc && u.has_cat && prec != kF16 && g_concat_sc && !g_calib.on && u.stride == 1;
+    const void *c2_in = ws.r1;
+    int c2_ldx = 0, res_ld = 0;
+    if (cat) {
+      DVSG_RUN(run_conv(prec, u.cat, false, X, B, h, w, ws.bufS, h, w, nullptr, 0, 0, 1, false, ws, &launch_idx, s, 0, 0,
+                        u.shortcut.cout));
+      res = ws.bufS;
+      res_h = ho; res_w = wo; res_stride = 1;
+      res_ld = u.cat.cout;
+      c2_in = ws.bufS + (size_t)u.shortcut.cout * sizeof(float);   // (f32s: 32 values are 128 bytes too)
+      c2_ldx = u.cat.cout;
+    } else {
     if (u.has_shortcut && !fuse_sc) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
       DVSG_RUN(run_conv(prec, u.shortcut, f16_pairs(net, u.block, kKindSc), X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws,
                         &launch_idx, s));
@@ -498,6 +521,7 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       res_h = ho; res_w = wo; res_stride = 1;
     }
     DVSG_RUN(run_conv(prec, u.c1, f16_pairs(net, u.block, kKindC1), X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+    }
     if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
       const bool pcs = prec == kF32S;
@@ -518,11 +542,11 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       DVSG_RUN(launch_conv3x3_1x1(f, s));
     } else {
       DVSG_RUN(calib_record(calib_slot + 1, ws.r1, (long)B * h * w, u.c2.cin, s));
-      DVSG_RUN(run_conv(prec, u.c2, f16_pairs(net, u.block, kKindC2), ws.r1, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
-                        &launch_idx, s));
+      DVSG_RUN(run_conv(prec, u.c2, f16_pairs(net, u.block, kKindC2), c2_in, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
+                        &launch_idx, s, c2_ldx));
       DVSG_RUN(calib_record(calib_slot + 2, ws.r2, (long)B * ho * wo, u.c3.cin, s));
       DVSG_RUN(run_conv(prec, u.c3, f16_pairs(net, u.block, kKindC3), ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true,
-                        ws, &launch_idx, s));
+                        ws, &launch_idx, s, 0, res_ld));
     }
     h = ho; w = wo;
     DVSG_TAP(stage, Y, h, w, u.depth);
@@ -719,6 +743,28 @@ int dvsg_locnet_create(int n_arrays, const char *const *names, const float *cons
       if ((rc = make_conv(net, m, sc + "/conv1", &unit.c1))) return bail(rc);
       if ((rc = make_conv(net, m, sc + "/conv2", &unit.c2))) return bail(rc);
       if ((rc = make_conv(net, m, sc + "/conv3", &unit.c3))) return bail(rc);
+      if (unit.has_shortcut && unit.shortcut.cin % 64 == 0 && unit.shortcut.cin > 64) {
+        // [shortcut rows | conv1 rows]: device-to-device copies of the two layers' float32 rows, f32s pieces and biases
+        const ConvLayer &a = unit.shortcut, &b = unit.c1;
+        unit.cat = ConvLayer{1, a.cin, a.cout + b.cout, 1, false};
+        const size_t ka = (size_t)a.cout * a.cin, kb = (size_t)b.cout * b.cin;
+        void *w = nullptr, *ws2 = nullptr, *bi = nullptr;
+        if (hipMalloc(&w, (ka + kb) * sizeof(float)) != hipSuccess || hipMalloc(&ws2, 2 * (ka + kb) * sizeof(_Float16)) != hipSuccess ||
+            hipMalloc(&bi, (a.cout + b.cout) * sizeof(float)) != hipSuccess)
+          return bail(fail(DVSG_ERR_HIP, "hipMalloc failed"));
+        net->allocs.push_back(w); net->allocs.push_back(ws2); net->allocs.push_back(bi);
+        hipError_t e = hipMemcpy(w, a.wt, ka * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(static_cast<float *>(w) + ka, b.wt, kb * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ws2, a.wt32s, 2 * ka * sizeof(_Float16), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(static_cast<_Float16 *>(ws2) + 2 * ka, b.wt32s, 2 * kb * sizeof(_Float16), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(bi, a.bias, a.cout * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(static_cast<float *>(bi) + a.cout, b.bias, b.cout * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) return bail(fail(DVSG_ERR_HIP, "concatenating shortcut | conv1: %s", hipGetErrorString(e)));
+        unit.cat.wt = static_cast<float *>(w);
+        unit.cat.wt32s = static_cast<_Float16 *>(ws2);
+        unit.cat.bias = static_cast<float *>(bi);
+        unit.has_cat = true;
+      }
       net->units.push_back(unit);
       depth_in = unit.depth;
     }
@@ -914,6 +960,10 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "fuse_conv") == 0) {
     set_fuse_conv(value);
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "concat_sc") == 0) {
+    g_concat_sc = value != 0;
     return DVSG_OK;
   }
   if (std::strcmp(name, "fuse_shortcut") == 0) {

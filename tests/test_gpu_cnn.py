@@ -301,6 +301,29 @@ def test_tile_count_regimes(net, synthetic_weights, B, H, W):
     assert np.abs(net.forward(x, precision="f16").cpu().numpy() - F_ref).max() <= 5e-5
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 33, 47), (1, 8, 8), (1, 1, 1), (3, 130, 200), (1, 288, 512)])
+def test_shortcut_and_conv1_as_one_launch(net, precision, B, H, W):
+    """Blocks 2-4's opening units run `shortcut` (no ReLU) and `conv1` (ReLU) -- same input -- as ONE conv GEMM over their
+    concatenated weight rows: the output [M, depth + base] sits in one buffer, conv2 reads its last `base` columns and conv3
+    its first `depth` as residual through row strides ("concat_sc"; dvsg_debug_set_option 0 = two launches).  Same products in
+    the same K order; the tile decomposition (and with it where split-K / stream-K cut a K loop) may differ: every unit's
+    output and F_t agree to float32 re-association."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    x = torch.from_numpy(inputs.window_frames(17 * H + W, B, H, W)).cuda()
+    got = {}
+    try:
+        for v in (0, 1):
+            _lib.call("dvsg_debug_set_option", b"concat_sc", v)
+            got[v] = [net.tap(x, st, precision=precision).clone() for st in (5, 9, 15)] + [net.forward(x, precision=precision).clone()]
+    finally:
+        _lib.call("dvsg_debug_set_option", b"concat_sc", 1)
+    for a, b in zip(got[0], got[1]):
+        scale = max(1.0, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-6 * scale, float((a - b).abs().max()) / scale
+
+
 def test_bad_calls_are_rejected(net):
     import torch
     from coupe.dvsg_amd import DvsgError, _lib
