@@ -420,7 +420,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 clip-loop measurement reported beside the line")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the cfg2_tf_warp / cfg4_f16_4k objects (BASELINE configs[2] and configs[4]) reported beside the line")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f32x3", "f16"],
                     help="f32 (default, the reference's arithmetic: the headline number); f32s: float32 storage / "
                          "accumulation with products from two float16 pieces per operand (dtype f32x2f16); f16: float16 "
                          "activations, hi / lo float16 weight pairs")

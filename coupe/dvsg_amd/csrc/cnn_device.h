@@ -19,6 +19,30 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// "f32x3": eight float32 values -> their three bfloat16 pieces, x = p1 + p2 + p3 EXACTLY (round to nearest each time:
+// |x - p1| <= 2^-8 |x| is a float32 with <= 16 significant bits, |x - p1 - p2| <= 2^-16 |x| one with <= 8, which p3 holds;
+// bfloat16 has float32's exponent range, so this holds for every finite float32 above 2^-110).  Packed conversions
+// (v_cvt_pk_bf16_f32) and packed subtractions: ~40 VALU instructions per call.
+__device__ __forceinline__ void split_bf16x3(const floatx4 lo, const floatx4 hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+  const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const floatx2 v = {x[i], x[i + 1]};
+    const bf16x2 a = __builtin_convertvector(v, bf16x2);
+    const floatx2 r = v - __builtin_convertvector(a, floatx2);
+    const bf16x2 b = __builtin_convertvector(r, bf16x2);
+    const floatx2 r2 = r - __builtin_convertvector(b, floatx2);
+    const bf16x2 c = __builtin_convertvector(r2, bf16x2);
+    p1[i] = a[0]; p1[i + 1] = a[1];
+    p2[i] = b[0]; p2[i + 1] = b[1];
+    p3[i] = c[0]; p3[i + 1] = c[1];
+  }
+}
+
 __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

@@ -18,7 +18,10 @@ namespace dvsg {
 // kF32S: 4 bytes per value and float32 accumulation like kF32, but every product is formed on the float16
 // matrix cores from two float16 pieces per operand (22 significant bits down to |x| = 2^-3; conv_gemm.hip), and the activation
 // tensors between the layers hold those two pieces (P format, cnn_device.h) instead of one float32.
-enum Precision { kF32 = 0, kF16 = 1, kF32S = 2 };
+// kF32X ("f32x3"): float32 tensors everywhere, exactly as kF32; inside the 52 conv GEMMs every product is formed on the
+// bfloat16 matrix cores from THREE bfloat16 pieces per operand -- all 24 significant bits of both float32 operands, at any
+// magnitude -- as six v_mfma_f32_32x32x16_bf16 with float32 accumulation (conv_gemm_tile.h, X3).
+enum Precision { kF32 = 0, kF16 = 1, kF32S = 2, kF32X = 3 };
 inline size_t elem_size(int prec) { return prec == kF16 ? 2 : 4; }
 
 // Implicit-GEMM convolution (1x1 or 3x3, NHWC, C_in % 64 == 0 (f16) / 32 (f32), C_out % 64 == 0):
@@ -42,6 +45,8 @@ struct ConvGemm {
   const void *wt_packed = nullptr;   // kF16, optional: the rows of `wt` packed stage by stage for conv_gemm_wide16.hip (launch_pack_wide16, order 0)
   const void *wt_packed_a = nullptr; // ... in order 1, for its 128-byte-activation-row kernel
   const void *wt_packed_h = nullptr; // ... in order 2, for its 3x3 stride-1 kernel (a kernel row's taps from one staged run)
+  int x3 = 0;         // kF32 only: wt is the layer's packed bfloat16 piece stages (launch_pack_x3) and the products are formed
+                      // from three bfloat16 pieces per operand (conv_gemm_tile.h, X3); x, res, y stay float32
   int wsplit = 0;     // kF16: wt is the stacked layout [Cout/64][128][K] (64 hi rows, then 64 lo rows); kF32: wt is
                       // [Cout][K/32][32 hi halves | 32 lo halves] and products are formed from float16 pieces (conv_gemm.hip)
   // optional split-K scratch (small batches): partial-tile slabs and kSplitKMaxTiles zeroed int tickets
@@ -52,6 +57,11 @@ struct ConvGemm {
 constexpr int kSplitKMaxTiles = 512;                                   // tickets one launch may use
 constexpr size_t kSplitKSlabBytes = (size_t)512 * 2 * 128 * 128 * 4;   // 64 MiB: 512 workgroups x 2 partial 128x128 f32 tiles (stream-K tail)
 int launch_conv_gemm(const ConvGemm &p, hipStream_t s);
+// f32x3 weights: float32 wt [rows][K] (rows % 64 == 0, K % 32 == 0) -> per group of 64 rows and 32-k stage three 4 KB planes
+// of bfloat16 pieces [64 rows][32 k] (p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2)), row R's 16-byte chunk c at
+// position c ^ ((R >> 2) & 3): 6 bytes per weight, [rows / 64][K / 32][3][64][32]
+inline size_t x3_packed_bytes(int rows, int K) { return (size_t)rows * K * 6; }
+int launch_pack_x3(const float *wt, void *out, int rows, int K, hipStream_t s);
 // float16 mode, big launches: 256 x 128 tiles with 64-byte K stages (conv_gemm_wide16.hip); called by launch_conv_gemm
 int launch_conv_wide16(const ConvGemm &p, hipStream_t s);
 void set_wide16_min_tiles(int v);

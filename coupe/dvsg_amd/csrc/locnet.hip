@@ -39,9 +39,11 @@ struct ConvLayer {
   _Float16 *wt16q = nullptr, *wt16qa = nullptr, *wt16qh = nullptr;   // device, the PLAIN copy wt16 packed the same three ways
                               // (cin % 64 == 0, cout % 128 == 0 layers: what runs when a layer has no lo piece)
   _Float16 *wt32s = nullptr;  // device, "f32s" pieces [cout][k*k*cin/32][32 hi | 32 lo] (conv_gemm.hip SPLIT, T = float; not for conv1)
+  unsigned short *wt3x = nullptr;  // device, "f32x3" bfloat16 pieces, packed stage by stage (launch_pack_x3; not for conv1)
   float *bias = nullptr;      // device, [cout] float32
   const void *weights(int prec, bool split) const {
     if (prec == kF32S) return wt32s;
+    if (prec == kF32X) return wt3x;
     return prec == kF16 ? (split ? (const void *)wt16s : (const void *)wt16) : (const void *)wt;
   }
 };
@@ -220,6 +222,14 @@ int make_conv(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Con
   }
   if (int rc = pack_plain(net, L)) return rc;
   if (int rc = upload(net, wt32s, &L->wt32s)) return rc;
+  if (K % 32 == 0 && L->cout % 64 == 0) {   // "f32x3": three bfloat16 pieces per weight, packed stage by stage
+    void *pk = nullptr;
+    DVSG_HIP(hipMalloc(&pk, x3_packed_bytes(L->cout, K)));
+    net->allocs.push_back(pk);
+    if (int rc = launch_pack_x3(L->wt, pk, L->cout, K, nullptr)) return rc;
+    DVSG_HIP(hipStreamSynchronize(nullptr));
+    L->wt3x = static_cast<unsigned short *>(pk);
+  }
   return upload(net, shift, &L->bias);
 }
 
@@ -361,8 +371,9 @@ int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int
   p.splitk_scratch = ws.splitk_slabs;
   p.splitk_scratch_bytes = kSplitKSlabBytes;
   p.splitk_counters = ws.splitk_counters + (size_t)((*launch_idx)++ % kMaxConvLaunches) * kSplitKMaxTiles;
-  p.prec = prec == kF32S ? kF32 : prec;
+  p.prec = prec == kF32S || prec == kF32X ? kF32 : prec;
   p.wsplit = prec == kF32S || (prec == kF16 && pairs);
+  p.x3 = prec == kF32X;
   p.x = x; p.wt = L.weights(prec, p.wsplit != 0); p.bias = L.bias; p.res = res; p.y = y;
   if (prec == kF16 && pairs) {
     p.wt_packed = L.wt16p;
@@ -433,6 +444,10 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
   if (ws.total > workspace_bytes)
     return fail(DVSG_ERR_WORKSPACE, "locnet forward: workspace %zu bytes < required %zu", workspace_bytes, ws.total);
   const Dims d = root_dims(H, W);
+  // f32x3: float32 tensors throughout; conv1, the pools, block 1's fused kernel and the head are the float32 kernels
+  // themselves, the conv GEMMs multiply bfloat16 pieces (run_conv)
+  const int gprec = prec;
+  if (prec == kF32X) prec = kF32;
 
   // parity tap: copy (float32 run) or convert (float16 run) the stage's activation to act_out
   auto tap = [&](int stage, const void *act, int h, int w, int c) -> int {
@@ -506,7 +521,7 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
     const void *c2_in = ws.r1;
     int c2_ldx = 0, res_ld = 0;
     if (cat) {
-      DVSG_RUN(run_conv(prec, u.cat, false, X, B, h, w, ws.bufS, h, w, nullptr, 0, 0, 1, false, ws, &launch_idx, s, 0, 0,
+      DVSG_RUN(run_conv(gprec, u.cat, false, X, B, h, w, ws.bufS, h, w, nullptr, 0, 0, 1, false, ws, &launch_idx, s, 0, 0,
                         u.shortcut.cout));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
@@ -515,12 +530,12 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       c2_ldx = u.cat.cout;
     } else {
     if (u.has_shortcut && !fuse_sc) {  // 1x1 conv + BN, no ReLU (stride is 1 wherever depth changes)
-      DVSG_RUN(run_conv(prec, u.shortcut, f16_pairs(net, u.block, kKindSc), X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws,
+      DVSG_RUN(run_conv(gprec, u.shortcut, f16_pairs(net, u.block, kKindSc), X, B, h, w, ws.bufS, ho, wo, nullptr, 0, 0, 1, false, ws,
                         &launch_idx, s));
       res = ws.bufS;
       res_h = ho; res_w = wo; res_stride = 1;
     }
-    DVSG_RUN(run_conv(prec, u.c1, f16_pairs(net, u.block, kKindC1), X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
+    DVSG_RUN(run_conv(gprec, u.c1, f16_pairs(net, u.block, kKindC1), X, B, h, w, ws.r1, h, w, nullptr, 0, 0, 1, true, ws, &launch_idx, s));
     }
     if (fuse23) {  // block 1: conv2 + conv3 in one kernel
       ConvFused f;
@@ -542,10 +557,10 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       DVSG_RUN(launch_conv3x3_1x1(f, s));
     } else {
       DVSG_RUN(calib_record(calib_slot + 1, ws.r1, (long)B * h * w, u.c2.cin, s));
-      DVSG_RUN(run_conv(prec, u.c2, f16_pairs(net, u.block, kKindC2), c2_in, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
+      DVSG_RUN(run_conv(gprec, u.c2, f16_pairs(net, u.block, kKindC2), c2_in, B, h, w, ws.r2, ho, wo, nullptr, 0, 0, 1, true, ws,
                         &launch_idx, s, c2_ldx));
       DVSG_RUN(calib_record(calib_slot + 2, ws.r2, (long)B * ho * wo, u.c3.cin, s));
-      DVSG_RUN(run_conv(prec, u.c3, f16_pairs(net, u.block, kKindC3), ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true,
+      DVSG_RUN(run_conv(gprec, u.c3, f16_pairs(net, u.block, kKindC3), ws.r2, B, ho, wo, Y, ho, wo, res, res_h, res_w, res_stride, true,
                         ws, &launch_idx, s, 0, res_ld));
     }
     h = ho; w = wo;
@@ -594,7 +609,7 @@ int stabilize(const dvsg_locnet *net, int prec, const float *patches_t, const fl
               void *stream) {
   DVSG_REQUIRE(net && patches_t && u_t && s_t_pred && workspace, "dvsg_stabilize: NULL pointer");
   DVSG_REQUIRE(B > 0 && B <= 65535, "dvsg_stabilize: B=%d out of range", B);
-  DVSG_REQUIRE(prec == kF32 || prec == kF16 || prec == kF32S, "dvsg_stabilize: unknown precision %d", prec);
+  DVSG_REQUIRE(prec == kF32 || prec == kF16 || prec == kF32S || prec == kF32X, "dvsg_stabilize: unknown precision %d", prec);
   DVSG_REQUIRE(!mask || net->c_in == 21, "dvsg_stabilize_masked: the mask covers the 18 history channels of a 7-frame window");
   const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
   if (ws.total > workspace_bytes)
@@ -619,7 +634,7 @@ int stabilize_ring(const dvsg_locnet *net, int prec, const void *pool, int pool_
                    size_t workspace_bytes, void *stream) {
   DVSG_REQUIRE(net && pool && table && s_t_pred && workspace, "dvsg_stabilize_ring: NULL pointer");
   DVSG_REQUIRE(B > 0 && B <= 65535 && n_pool > 0, "dvsg_stabilize_ring: B=%d n_pool=%d out of range", B, n_pool);
-  DVSG_REQUIRE(prec == kF32 || prec == kF16 || prec == kF32S, "dvsg_stabilize_ring: unknown precision %d", prec);
+  DVSG_REQUIRE(prec == kF32 || prec == kF16 || prec == kF32S || prec == kF32X, "dvsg_stabilize_ring: unknown precision %d", prec);
   DVSG_REQUIRE(net->c_in == 21, "dvsg_stabilize_ring: the ring holds RGB frames, 7 per window");
   const Workspace ws = plan(static_cast<char *>(workspace), B, H, W);
   if (ws.total > workspace_bytes)
@@ -644,7 +659,8 @@ int conv_gemm_op(int prec, int wsplit, const void *x, const void *wt, const floa
   DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && res_stride >= 1, "dvsg_conv_gemm: bad shape");
   ConvGemm p;
   p.prec = prec;
-  p.wsplit = wsplit;
+  p.wsplit = wsplit == 1;
+  p.x3 = wsplit == 2;   // f32x3: packed bfloat16 piece stages
   p.x = x; p.wt = wt; p.bias = bias; p.res = res; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
@@ -748,20 +764,24 @@ int dvsg_locnet_create(int n_arrays, const char *const *names, const float *cons
         const ConvLayer &a = unit.shortcut, &b = unit.c1;
         unit.cat = ConvLayer{1, a.cin, a.cout + b.cout, 1, false};
         const size_t ka = (size_t)a.cout * a.cin, kb = (size_t)b.cout * b.cin;
-        void *w = nullptr, *ws2 = nullptr, *bi = nullptr;
+        void *w = nullptr, *ws2 = nullptr, *bi = nullptr, *w3 = nullptr;
         if (hipMalloc(&w, (ka + kb) * sizeof(float)) != hipSuccess || hipMalloc(&ws2, 2 * (ka + kb) * sizeof(_Float16)) != hipSuccess ||
-            hipMalloc(&bi, (a.cout + b.cout) * sizeof(float)) != hipSuccess)
+            hipMalloc(&bi, (a.cout + b.cout) * sizeof(float)) != hipSuccess || hipMalloc(&w3, 6 * (ka + kb)) != hipSuccess)
           return bail(fail(DVSG_ERR_HIP, "hipMalloc failed"));
-        net->allocs.push_back(w); net->allocs.push_back(ws2); net->allocs.push_back(bi);
+        net->allocs.push_back(w); net->allocs.push_back(ws2); net->allocs.push_back(bi); net->allocs.push_back(w3);
         hipError_t e = hipMemcpy(w, a.wt, ka * sizeof(float), hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipMemcpy(static_cast<float *>(w) + ka, b.wt, kb * sizeof(float), hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipMemcpy(ws2, a.wt32s, 2 * ka * sizeof(_Float16), hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipMemcpy(static_cast<_Float16 *>(ws2) + 2 * ka, b.wt32s, 2 * kb * sizeof(_Float16), hipMemcpyDeviceToDevice);
+        // (the f32x3 packing is by groups of 64 rows: the two layers' packed stages one behind the other)
+        if (e == hipSuccess) e = hipMemcpy(w3, a.wt3x, 6 * ka, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(static_cast<char *>(w3) + 6 * ka, b.wt3x, 6 * kb, hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipMemcpy(bi, a.bias, a.cout * sizeof(float), hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipMemcpy(static_cast<float *>(bi) + a.cout, b.bias, b.cout * sizeof(float), hipMemcpyDeviceToDevice);
         if (e != hipSuccess) return bail(fail(DVSG_ERR_HIP, "concatenating shortcut | conv1: %s", hipGetErrorString(e)));
         unit.cat.wt = static_cast<float *>(w);
         unit.cat.wt32s = static_cast<_Float16 *>(ws2);
+        unit.cat.wt3x = static_cast<unsigned short *>(w3);
         unit.cat.bias = static_cast<float *>(bi);
         unit.has_cat = true;
       }
@@ -836,6 +856,22 @@ int dvsg_locnet_forward_f32s(const dvsg_locnet_t *net, const float *patches, int
                  as_stream(stream));
 }
 
+int dvsg_locnet_forward_f32x3(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, float *F_t,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(F_t, "dvsg_locnet_forward_f32x3: NULL F_t");
+  return forward(net, kF32X, patches, B, H, W, F_t, -1, nullptr, 0, nullptr, workspace, workspace_bytes,
+                 as_stream(stream));
+}
+
+int dvsg_locnet_forward_tap_f32x3(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
+                                  float *act_out, size_t act_out_bytes, int *act_dims_host, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  DVSG_REQUIRE(act_out && act_dims_host, "dvsg_locnet_forward_tap_f32x3: NULL pointer");
+  DVSG_REQUIRE(stage >= 0 && stage <= 18, "dvsg_locnet_forward_tap_f32x3: stage %d outside [0,18]", stage);
+  return forward(net, kF32X, patches, B, H, W, nullptr, stage, act_out, act_out_bytes, act_dims_host, workspace,
+                 workspace_bytes, as_stream(stream));
+}
+
 int dvsg_locnet_forward_tap_f32s(const dvsg_locnet_t *net, const float *patches, int B, int H, int W, int stage,
                                  float *act_out, size_t act_out_bytes, int *act_dims_host, void *workspace,
                                  size_t workspace_bytes, void *stream) {
@@ -882,6 +918,17 @@ int dvsg_conv_gemm_f32s(const void *x, const void *wt_pieces, const float *bias,
                         size_t scratch_bytes, void *stream) {
   return conv_gemm_op(kF32, 1, x, wt_pieces, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
                       scratch_bytes, stream);
+}
+
+int dvsg_conv_gemm_f32x3(const float *x, const void *wt_packed, const float *bias, const float *res, float *y, int B, int H,
+                         int W, int Cin, int Cout, int ksize, int stride, int relu, int res_stride, void *scratch,
+                         size_t scratch_bytes, void *stream) {
+  return conv_gemm_op(kF32, 2, x, wt_packed, bias, res, y, B, H, W, Cin, Cout, ksize, stride, relu, res_stride, scratch,
+                      scratch_bytes, stream);
+}
+
+int dvsg_pack_weights_f32x3(const float *wt, void *wt_packed, int Cout, int K, void *stream) {
+  return launch_pack_x3(wt, wt_packed, Cout, K, as_stream(stream));
 }
 
 int dvsg_f32_to_pieces(const float *x, void *y, size_t n, void *stream) {
@@ -1105,8 +1152,15 @@ int dvsg_stabilize_f16(const dvsg_locnet_t *net, const float *patches_t, const f
   return stabilize(net, kF16, patches_t, u_t, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
 }
 
+int dvsg_stabilize_f32x3(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B, int H, int W,
+                         float *s_t_pred, float *F_t, float *x_s, float *y_s, void *workspace, size_t workspace_bytes,
+                         void *stream) {
+  return stabilize(net, kF32X, patches_t, u_t, nullptr, B, H, W, s_t_pred, F_t, x_s, y_s, workspace, workspace_bytes, stream);
+}
+
 static int ring_precision(int precision) {
-  return precision == DVSG_PRECISION_F32 ? kF32 : precision == DVSG_PRECISION_F16 ? kF16 : precision == DVSG_PRECISION_F32S ? kF32S : -1;
+  return precision == DVSG_PRECISION_F32 ? kF32 : precision == DVSG_PRECISION_F16 ? kF16 : precision == DVSG_PRECISION_F32S ? kF32S
+         : precision == DVSG_PRECISION_F32X3 ? kF32X : -1;
 }
 
 int dvsg_stabilize_ring_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool, const int32_t *table,

@@ -79,7 +79,9 @@ class StabNet:
         # "f32": exact float32 matrix cores (the reference's arithmetic, the path of record); "f32s": float32 width and
         # accumulation, products from two float16 pieces per operand (2x faster; float32-GEMM-level differences while operand
         # magnitudes stay above ~2^-3 .. 0.03, fewer bits below: include/dvsg_amd.h);
-        # "f16": float16 activations, hi / lo float16 conv weights
+        # "f32x3": float32 tensors and accumulation, conv products from three bfloat16 pieces per operand (all 24 bits of both
+        # operands at any magnitude; as close to float64 as "f32" is, tests/test_gpu_f32x3.py); "f16": float16 activations,
+        # hi / lo float16 conv weights
         self.precision = "f32"
         # eval_train.py's graph (eval_train.py:43-45): F_t = localizationNet(patches_t * random mask); False = model.py's
         self.masked = False

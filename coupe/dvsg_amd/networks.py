@@ -29,9 +29,11 @@ def scale_RGB(rgb):
 def _entry(base, precision):
     """C entry point for a precision: "f32" (exact float32 matrix cores, the reference's arithmetic),
     "f32s" (float32 storage and accumulation, products from two float16 pieces per operand: 22 significant
-    bits for |x| >= 2^-3, an absolute step of 2^-24 below -- include/dvsg_amd.h) or "f16" (float16 activations, hi / lo float16 weight pairs)."""
-    if precision not in ("f32", "f32s", "f16"):
-        raise ValueError("precision must be 'f32', 'f32s' or 'f16', got %r" % (precision,))
+    bits for |x| >= 2^-3, an absolute step of 2^-24 below -- include/dvsg_amd.h), "f32x3" (float32 tensors and accumulation,
+    conv products from three bfloat16 pieces per operand: all 24 bits of both operands at any magnitude) or "f16" (float16
+    activations, hi / lo float16 weight pairs)."""
+    if precision not in ("f32", "f32s", "f32x3", "f16"):
+        raise ValueError("precision must be 'f32', 'f32s', 'f32x3' or 'f16', got %r" % (precision,))
     return "%s_%s" % (base, precision)
 
 
@@ -136,7 +138,7 @@ class LocNet(object):
             join.record(side)
             cur.wait_event(join)
 
-    _PRECISION_CODE = {"f32": 0, "f16": 1, "f32s": 2}   # DVSG_PRECISION_* of include/dvsg_amd.h
+    _PRECISION_CODE = {"f32": 0, "f16": 1, "f32s": 2, "f32x3": 3}   # DVSG_PRECISION_* of include/dvsg_amd.h
 
     def _check_ring(self, pool, table):
         import torch
@@ -172,7 +174,7 @@ class LocNet(object):
         import torch
         B, H, W = self._check_ring(pool, table)
         if precision not in self._PRECISION_CODE:
-            raise ValueError("precision must be 'f32', 'f32s' or 'f16', got %r" % (precision,))
+            raise ValueError("precision must be 'f32', 'f32s', 'f32x3' or 'f16', got %r" % (precision,))
         if tuple(out.shape) != (B, H, W, 3) or F.numel() != B * 50:
             raise ValueError("out must be [B,H,W,3] and F_t [B,25,2]")
         for name, t, n in (("s_t_pred", out, None), ("F_t", F, None), ("x_s", xs, B * H * W), ("y_s", ys, B * H * W)):

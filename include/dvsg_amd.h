@@ -251,6 +251,40 @@ int dvsg_conv_gemm_f32s(const void *x, const void *wt_pieces, const float *bias,
 int dvsg_f32_to_pieces(const float *x, void *y, size_t n, void *stream);   /* n % 32 == 0 */
 int dvsg_pieces_to_f32(const void *x, float *y, size_t n, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * "f32x3": float32 tensors everywhere -- boundary, workspace, every activation between the layers, exactly as the *_f32
+ * entry points -- and float32 accumulation; inside the 52 1x1 / 3x3 convolutions every PRODUCT is formed on the bfloat16
+ * matrix cores from THREE bfloat16 pieces per operand, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1),
+ * x3 = bf16(x - x1 - x2) (round to nearest).  bfloat16 has float32's exponent range and 8 significant bits, so the three
+ * pieces hold all 24 significant bits of ANY finite float32 operand above 2^-110 -- no magnitude condition, unlike the two
+ * float16 pieces of "f32s" -- and each piece product is exact in float32.  Of the nine cross terms of a w the six largest
+ * (a1 w1, a1 w2, a2 w1, a2 w2, a1 w3, a3 w1) are accumulated, six v_mfma_f32_32x32x16_bf16 where the exact path issues
+ * eight v_mfma_f32_32x32x2_f32 at 2.7 x the matrix-core time; the dropped a2 w3 + a3 w2 + a3 w3 are bounded by 2^-23 |a w|
+ * -- one rounding of a float32 multiply; 2^-27 typically -- and each MFMA rounds its 16-term sum into the float32
+ * accumulator once, so a K-long dot product sees 6 K / 16 accumulator roundings where the float32 FMA chain sees K.
+ * Activations are split in registers behind the LDS fragment read; weights once at load (dvsg_locnet_create;
+ * dvsg_pack_weights_f32x3 for a single layer).  conv1, the pools, block 1's fused conv2 + conv3, the dense head, the TPS
+ * solve and the warp are the float32 kernels themselves.  Measured against a float64 evaluation it is as close as the
+ * exact path is (tests/test_gpu_f32x3.py).  A separately named precision: dvsg_*_f32 stays the path whose matrix
+ * instructions are float32 ones.
+ * ------------------------------------------------------------------------------------- */
+int dvsg_locnet_forward_f32x3(const dvsg_locnet_t *net, const float *patches, int B, int H, int W,
+                              float *F_t, void *workspace, size_t workspace_bytes, void *stream);
+int dvsg_locnet_forward_tap_f32x3(const dvsg_locnet_t *net, const float *patches, int B, int H,
+                                  int W, int stage, float *act_out, size_t act_out_bytes,
+                                  int *act_dims_host, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+int dvsg_stabilize_f32x3(const dvsg_locnet_t *net, const float *patches_t, const float *u_t, int B,
+                         int H, int W, float *s_t_pred, float *F_t, float *x_s, float *y_s,
+                         void *workspace, size_t workspace_bytes, void *stream);
+/* One layer in that mode: x, res, y float32 as for dvsg_conv_gemm_f32 (Cin % 32 == 0, Cout % 64 == 0); wt_packed is what
+ * dvsg_pack_weights_f32x3 makes of the float32 matrix wt [Cout][K] (K = ksize^2 Cin, the layout dvsg_conv_gemm_f32 takes):
+ * 6 Cout K bytes, per group of 64 output channels and 32-k stage three 4 KB planes of bfloat16 pieces. */
+int dvsg_conv_gemm_f32x3(const float *x, const void *wt_packed, const float *bias, const float *res,
+                         float *y, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                         int relu, int res_stride, void *scratch, size_t scratch_bytes, void *stream);
+int dvsg_pack_weights_f32x3(const float *wt, void *wt_packed, int Cout, int K, void *stream);
+
 /* x, wt, res, y are float16 (Cin % 64 == 0); bias float32. */
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y,
                        int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
@@ -312,6 +346,7 @@ int dvsg_window_gather_f32(const float *pool, int n_pool, int H, int W, const in
 #define DVSG_PRECISION_F32 0
 #define DVSG_PRECISION_F16 1
 #define DVSG_PRECISION_F32S 2
+#define DVSG_PRECISION_F32X3 3
 int dvsg_stabilize_ring_f32(const dvsg_locnet_t *net, int precision, const float *pool, int n_pool,
                             const int32_t *table, int B, int H, int W, float *s_t_pred, float *F_t, float *x_s,
                             float *y_s, void *workspace, size_t workspace_bytes, void *stream);

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 # -- its 22-bit products cost nothing here --, f16 1.2e-2 / 2.4e-3 (pool5 1.8e-2 / 3.1e-3): float16 ACTIVATIONS (11 bits)
 # through channels whose folded BatchNorm scale is large; at 720p |F_t| ~ 1 means 1.2e-2 x 640 = 8 px -- on a checkpoint
 # like this one the float16 mode does not meet the 1e-3 pixel tolerance it meets on the friendly one.
-BOUNDS = {"f32": (None, None, None), "f32s": (6e-5, 8e-6, 6e-5), "f16": (4e-2, 8e-3, 6e-2)}
+BOUNDS = {"f32": (None, None, None), "f32x3": (None, None, None), "f32s": (6e-5, 8e-6, 6e-5), "f16": (4e-2, 8e-3, 6e-2)}
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +69,7 @@ def test_stress_checkpoint_f_t_in_every_precision(stress, H, W, seed):
         rel = np.abs(F - rF).max() / fnorm
         prel = np.abs(pool - rpool).max() / pnorm
         print("stress %dx%d %s vs float64 arbiter: F_t rel %.3g (abs %.3g), pool5 rel %.3g" % (H, W, precision, rel, np.abs(F - rF).max(), prel))
-        if precision == "f32":
+        if precision in ("f32", "f32x3"):   # f32x3 is held to the exact path's bound: within twice the float32 oracle's own error
             if not (rel <= 2.0 * o_rel + 1e-6 and prel <= 2.0 * o_prel + 1e-6):
                 failures.append((precision, rel, prel))
         elif not (rel < (b_small if H < 100 else b_big) and prel < (b_pool if H < 100 else b_pool / 4)):

@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--variants", default="1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", default="uniq")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f16"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32s", "f32x3", "f16"])
     ap.add_argument("--rep", type=int, default=20,
                     help="back-to-back launches per timing (1 = isolated launches: the clock governor has not ramped "
                          "and short kernels read 10-15 %% low, DESIGN.md 5.0)")
@@ -73,12 +73,16 @@ def main():
             hi = wt.half()
             lo = (wt - hi.float()).half()
             wt = torch.cat([hi.reshape(cout, K // 32, 32), lo.reshape(cout, K // 32, 32)], 2).contiguous()
+        if args.precision == "f32x3":  # bfloat16 piece stages (dvsg_pack_weights_f32x3)
+            packed = torch.empty((cout * K * 6,), dtype=torch.uint8, device=dev)
+            _lib.call("dvsg_pack_weights_f32x3", wt.data_ptr(), packed.data_ptr(), cout, K, stream)
+            wt = packed
         bias = torch.rand((cout,), generator=g, device=dev) - 0.5
         res = (torch.rand((B, ho, wo, cout), generator=g, device=dev) - 0.5).to(dt) if has_res else None
         y = torch.empty((B, ho, wo, cout), device=dev, dtype=dt)
         M = B * ho * wo
         flops = 2.0 * M * cout * K
-        nbytes = x.element_size() * (x.numel() + wt.numel() + y.numel() * (2 if has_res else 1))
+        nbytes = x.element_size() * (x.numel() + cout * K + y.numel() * (2 if has_res else 1))
         times = {v: [] for v in variants}
 
         def run():
