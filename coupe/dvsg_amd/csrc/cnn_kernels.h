@@ -124,6 +124,11 @@ constexpr int kConv1LdH = 168;
 // conv1's input: the window tensor [B,H,W,21] float32 the reference feeds (eval.py:106-110), or -- SURVEY.md 8f-1/-2 --
 // a pool of RGB frames [n_pool,H,W,3] (float32 in [0,1], or raw uint8 whose / 255. is fused) plus the table [B,7] of
 // the pool frame in each window slot, oldest to newest: the np.concatenate of eval.py:103-104 happens in the load stage.
+// wt1x ("f32x3" precision only): bfloat16 pieces [14][3][64][kConv1X3Ld]: stage 2 kh + half holds taps [80 half, 80 half + 80)
+// of kernel row kh (position p = tap + 1 behind the zero tap, as in wt1h; positions 148..159 zero) as three piece planes,
+// p1 = bf16(w), p2 = bf16(w - p1), p3 = bf16(w - p1 - p2); rows zero-padded from 80 to 88.
+constexpr int kConv1X3Ld = 88;
+constexpr int kConv1X3StageElems = 3 * 64 * kConv1X3Ld;   // 16 896 bfloat16 per half kernel row
 enum Conv1SrcKind { kSrcWindow = 0, kSrcRingF32 = 1, kSrcRingU8 = 2 };
 struct Conv1Src {
   const void *base;   // window tensor, or frame pool
@@ -133,7 +138,7 @@ struct Conv1Src {
                                  // by mask[b] (one plane: the warp of an all-ones image is the same in every channel) in the load stage
 };
 int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *wt1, const void *wt1h, const void *wt1s,
-                 const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
+                 const void *wt1x, const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s);
 
 // 3x3 stride-2 TF-SAME max pool (slim resnet root), C % 8 == 0.
 int launch_maxpool(int prec, const void *x, void *y, int B, int H, int W, int C, int Ho, int Wo, int pad_top,

@@ -1520,6 +1520,178 @@ void conv1_split_kernel(const Conv1Src src, const _Float16 *__restrict__ wt1s, c
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// "f32x3" conv1: float32 in, float32 out, every product from THREE bfloat16 pieces per operand (conv_gemm_tile.h, X3: all 24
+// bits of both operands, six of the nine cross terms, the five small ones in their own accumulators).  Built like
+// conv1_split_kernel: the scaled input row is split ONCE while it is staged -- three bfloat16 images of the row in LDS, 33 KB
+// -- so the loop holds LDS reads and MFMAs only (a split in registers would be ~40 VALU per fragment that the matrix pipe
+// does not hide, tools/x3_overlap_probe.hip).  The weight pieces of a kernel row are 3 x 64 x 160 bfloat16 = 61 KB, too many
+// for two workgroups per CU next to the input images: a kernel row is staged as two HALVES of 80 taps (5 MFMA steps each,
+// [piece][64][88] bfloat16 = 33 KB; 176-byte rows: 11 sixteen-byte slots, odd, so a ds_read_b128 lane group is conflict-free),
+// 14 stages per tile, the input images restaged at every other one.
+// ----------------------------------------------------------------------------------------
+constexpr int C1X_SEG = 5504;                        // bfloat16 per staged image of the row (1 + 5481 + tail; reads reach 5495)
+constexpr int C1X_IN4 = (C1X_SEG / 4 + 255) / 256;     // 6 groups of four elements per thread
+constexpr int C1X_WBYTES = kConv1X3StageElems * 2;   // 33 792 bytes per half kernel row
+constexpr int C1X_WS = C1_TILE * C1_LDC * 4;         // the weight stage also holds the epilogue's transpose tile (34 816)
+static_assert(C1X_WS >= C1X_WBYTES, "weight stage smaller than a half kernel row");
+
+template <int SRC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv1_x3_kernel(const Conv1Src src, const unsigned short *__restrict__ wt1x, const float *__restrict__ bias,
+                     float *__restrict__ y, int H, int W, int Ho, int Wo, int wtiles) {
+  constexpr int NT = 256;
+  constexpr int WLOADS = (C1X_WBYTES / 16 + NT - 1) / NT;    // 9 float4
+  __shared__ __attribute__((aligned(16))) char w_s[C1X_WS];
+  __shared__ __attribute__((aligned(16))) unsigned in_p[3][C1X_SEG / 2];  // two bfloat16 per word
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;   // wave w: pixels [32 w, 32 w + 32) x all 64 channels (two 32-channel blocks)
+
+  int blk = xcd_remap(blockIdx.x, gridDim.x);  // see conv1_kernel
+  const int wt_i = blk % wtiles;
+  blk /= wtiles;
+  const int ho = blk % Ho;
+  const int b = blk / Ho;
+  const int wo0 = wt_i * C1_TILE;
+
+  typedef typename Conv1RowSel<NT, C1X_IN4, SRC>::type Row;
+  Row row;
+  row.init(src, tid, b, wo0, H, W, C1X_SEG);
+  if constexpr (Row::kRing) {
+    for (int e = tid; e < C1X_SEG / 2; e += NT) in_p[0][e] = in_p[1][e] = in_p[2][e] = 0u;
+  }
+  typename Row::Data rd;
+  floatx4 w_reg[WLOADS];
+  auto load_stage = [&](int st) __attribute__((always_inline)) {   // stage st: kernel row st / 2, taps [80 (st & 1), + 80)
+    if ((st & 1) == 0) row.load(rd, 2 * ho + (st >> 1) - 3);
+    const floatx4 *wsrc = reinterpret_cast<const floatx4 *>(wt1x + (size_t)st * kConv1X3StageElems);
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int q = tid + NT * i;
+      w_reg[i] = wsrc[q < C1X_WBYTES / 16 ? q : 0];
+    }
+  };
+  auto pieces = [](float v, __bf16 &p1, __bf16 &p2, __bf16 &p3) __attribute__((always_inline)) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+  };
+  auto store_stage = [&](int st) __attribute__((always_inline)) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if ((st & 1) == 0) {
+      if constexpr (Row::kRing) {
+        row.scatter(rd, [&](int e, float v) __attribute__((always_inline)) {
+          __bf16 p1, p2, p3;
+          pieces(v, p1, p2, p3);
+          reinterpret_cast<__bf16 *>(in_p[0])[e] = p1;
+          reinterpret_cast<__bf16 *>(in_p[1])[e] = p2;
+          reinterpret_cast<__bf16 *>(in_p[2])[e] = p3;
+        });
+      } else {
+#pragma unroll
+        for (int i = 0; i < C1X_IN4; ++i) {
+          const int q = tid + NT * i;
+          const floatx4 v = row.scaled(rd, i);   // then the three pieces
+          bf16x4 v1, v2, v3;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            __bf16 p1, p2, p3;
+            pieces(v[j], p1, p2, p3);
+            v1[j] = p1; v2[j] = p2; v3[j] = p3;
+          }
+          if (q < C1X_SEG / 4) {
+            reinterpret_cast<bf16x4 *>(in_p[0])[q] = v1;
+            reinterpret_cast<bf16x4 *>(in_p[1])[q] = v2;
+            reinterpret_cast<bf16x4 *>(in_p[2])[q] = v3;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WLOADS; ++i) {
+      const int q = tid + NT * i;
+      if (q < C1X_WBYTES / 16) reinterpret_cast<floatx4 *>(w_s)[q] = w_reg[i];
+    }
+  };
+
+  floatx16 acc[2], accs[2];   // [channel block]: the large cross term, the five small ones
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[ni][q] = accs[ni][q] = 0.f;
+
+  load_stage(0);
+  for (int st = 0; st < 14; ++st) {
+    __syncthreads();  // everyone is done reading the previous stage
+    store_stage(st);
+    __syncthreads();
+    if (st + 1 < 14) load_stage(st + 1);
+    __builtin_amdgcn_sched_barrier(0);  // prefetch stays ahead of the MFMA loop
+    // word index of the lane's first tap pair: (42 pixel + 80 (st & 1) + 8 h) / 2
+    const int a0 = kConv1Cin * (wave * 32 + r) + 40 * (st & 1) + 4 * h;
+    const __bf16 *b0 = reinterpret_cast<const __bf16 *>(w_s) + r * kConv1X3Ld + 8 * h;
+    struct Frag {
+      union {
+        unsigned u[4];
+        bf16x8 v;
+      } a[3];
+      bf16x8 bw[3][2];
+    };
+    auto read_frag = [&](Frag &f, int t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.a[p].u[j] = in_p[p][a0 + 8 * t + j];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          f.bw[p][ni] = *reinterpret_cast<const bf16x8 *>(b0 + (p * 64 + ni * 32) * kConv1X3Ld + 16 * t);
+      }
+    };
+    Frag fr[2];
+    read_frag(fr[0], 0);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      if (t + 1 < 5) read_frag(fr[(t + 1) & 1], t + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that do not need them
+      const Frag &f = fr[t & 1];
+#define DVSG_C1X_TERM(C, PA, PB) \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) C[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA].v, f.bw[PB][ni], C[ni], 0, 0, 0)
+      DVSG_C1X_TERM(accs, 2, 0);
+      DVSG_C1X_TERM(accs, 0, 2);
+      DVSG_C1X_TERM(accs, 1, 1);
+      DVSG_C1X_TERM(accs, 1, 0);
+      DVSG_C1X_TERM(accs, 0, 1);
+      DVSG_C1X_TERM(acc, 0, 0);
+#undef DVSG_C1X_TERM
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: join the two accumulators, transpose through the (idle) weight stage
+  float *Cs = reinterpret_cast<float *>(w_s);
+  __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      Cs[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h) * C1_LDC + ni * 32 + r] = acc[ni][q] + accs[ni][q];
+  __syncthreads();
+  const int col4 = tid & 15, row0 = tid >> 4;
+  const float4 b4 = *reinterpret_cast<const float4 *>(bias + 4 * col4);
+#pragma unroll 4
+  for (int row = row0; row < C1_TILE; row += 16) {
+    if (wo0 + row >= Wo) break;
+    float4 v = *reinterpret_cast<const float4 *>(Cs + row * C1_LDC + 4 * col4);
+    v.x = fmaxf(v.x + b4.x, 0.f);
+    v.y = fmaxf(v.y + b4.y, 0.f);
+    v.z = fmaxf(v.z + b4.z, 0.f);
+    v.w = fmaxf(v.w + b4.w, 0.f);
+    store4(y + (((size_t)b * Ho + ho) * Wo + wo0 + row) * 64 + 4 * col4, v);
+  }
+}
+
 // max pool on a P-format tensor ("f32s"): the pieces are joined (exact), compared, and the maximum's pieces stored
 __global__ __launch_bounds__(256) void maxpool_p_kernel(const void *__restrict__ x, void *__restrict__ y, int H, int W,
                                                        int C4, int Ho, int Wo, int pad_top, int pad_left, size_t total) {
@@ -1575,7 +1747,7 @@ int g_conv1_variant = 0;  // dvsg_debug_set_option("conv1_variant", v): 0 = auto
 void set_conv1_variant(int v) { g_conv1_variant = v; }
 
 int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *wt1, const void *wt1h, const void *wt1s,
-                 const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s) {
+                 const void *wt1x, const float *bias, void *y, int B, int H, int W, int Ho, int Wo, hipStream_t s) {
   const int wtiles = ceil_div(Wo, C1_TILE);
   const long blocks = (long)wtiles * Ho * B;
   DVSG_REQUIRE(blocks > 0 && blocks < (1L << 31), "conv1: grid of %ld workgroups out of range", blocks);
@@ -1594,6 +1766,7 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
 #define DVSG_K_F32(SRC) conv1_kernel<4, float, SRC>
 #define DVSG_K_F16(SRC) conv1_f16_kernel<_Float16, (SRC) & 7>   /* A/B kernel: never launched with a mask */
 #define DVSG_K_SPLIT(SRC) conv1_split_kernel<float, SRC>
+#define DVSG_K_X3(SRC) conv1_x3_kernel<SRC>
 #define DVSG_C1(KERNEL, NTHREADS, WPTR, YPTR)                                                                            \
   do {                                                                                                                   \
     switch (SRC) {                                                                                                       \
@@ -1611,7 +1784,10 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
       default: hipLaunchKernelGGL((KERNEL(13)), grid, dim3(NTHREADS), 0, s, src, WPTR, bias, YPTR, H, W, Ho, Wo, wtiles); break; \
     }                                                                                                                    \
   } while (0)
-  if (out_prec == kF32S) {
+  if (out_prec == kF32X && !wt1x) return fail(DVSG_ERR_UNSUPPORTED, "conv1: the f32x3 precision needs the bfloat16 piece weights");
+  if (out_prec == kF32X) {
+    DVSG_C1(DVSG_K_X3, 256, static_cast<const unsigned short *>(wt1x), static_cast<float *>(y));
+  } else if (out_prec == kF32S) {
     DVSG_C1(DVSG_K_SPLIT, 256, static_cast<const _Float16 *>(wt1s), static_cast<float *>(y));
   } else if (out_prec == kF16 && wt1h && g_conv1_variant == 3 && !src.mask) {   // A/B: one output row per workgroup
     DVSG_C1(DVSG_K_F16, 256, static_cast<const _Float16 *>(wt1h), static_cast<_Float16 *>(y));
@@ -1671,6 +1847,7 @@ int launch_conv1(int out_prec, const Conv1Src &src, int src_kind, const float *w
 #undef DVSG_K_F32
 #undef DVSG_K_F16
 #undef DVSG_K_SPLIT
+#undef DVSG_K_X3
   return check_launch("conv1_kernel");
 }
 

@@ -267,9 +267,37 @@ int make_conv1(dvsg_locnet *net, const ArrayMap &m, const std::string &scope, Co
         wts[(((size_t)kh * 2 + 0) * 64 + n) * kConv1LdH + k + 1] = hi;
         wts[(((size_t)kh * 2 + 1) * 64 + n) * kConv1LdH + k + 1] = (_Float16)((w32 - (float)hi) * 2048.0f);
       }
+  // "f32x3" pieces [14][3][64][kConv1X3Ld] bfloat16 (cnn_kernels.h): stage 2 kh + half, position p = tap + 1
+  auto bf16_rn = [](float f) -> unsigned short {   // round to nearest even on the upper 16 bits (finite inputs)
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+  };
+  auto bf16_val = [](unsigned short hbits) -> float {
+    const uint32_t u = (uint32_t)hbits << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  std::vector<unsigned short> wtx((size_t)14 * kConv1X3StageElems, 0);
+  for (int kh = 0; kh < 7; ++kh)
+    for (int n = 0; n < 64; ++n)
+      for (int pos = 1; pos <= kConv1K; ++pos) {
+        const float w32 = wt[((size_t)kh * 64 + n) * kConv1Ld + pos];
+        const unsigned short p1 = bf16_rn(w32);
+        const float r1 = w32 - bf16_val(p1);
+        const unsigned short p2 = bf16_rn(r1);
+        const unsigned short p3 = bf16_rn(r1 - bf16_val(p2));
+        const size_t base = (size_t)(2 * kh + pos / 80) * kConv1X3StageElems + (size_t)n * kConv1X3Ld + pos % 80;
+        wtx[base] = p1;
+        wtx[base + 64 * kConv1X3Ld] = p2;
+        wtx[base + 2 * 64 * kConv1X3Ld] = p3;
+      }
   if (int rc = upload(net, wt, &L->wt)) return rc;
   if (int rc = upload(net, wth, &L->wt16)) return rc;
   if (int rc = upload(net, wts, &L->wt32s)) return rc;
+  if (int rc = upload(net, wtx, &L->wt3x)) return rc;
   return upload(net, shift, &L->bias);
 }
 
@@ -306,6 +334,8 @@ inline bool f16_pairs(const dvsg_locnet *net, int block, int kind) {
 }
 // block 1's shortcut conv inside the fused conv2 + conv3 kernel (dvsg_debug_set_option("fuse_shortcut", 0): A/B)
 int g_fuse_shortcut = 1;
+int g_x3_conv1 = 1;  // dvsg_debug_set_option("x3_conv1", 0): the f32x3 precision with the float32 conv1 kernel (A/B)
+int g_x3_fuse = 1;   // dvsg_debug_set_option("x3_fuse", v): A/B of block 1's fusion in the f32x3 precision (forward())
 // blocks 2-4's opening units: shortcut + conv1 as one launch (dvsg_debug_set_option("concat_sc", 0): A/B)
 int g_concat_sc = 1;
 
@@ -482,8 +512,8 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
   // root: conv1 (+ fused scale_RGB; f32 multiply, output in `prec`) -> bufA, max pool -> bufB
   {
   MarkerRange mr("dvsg/conv1");
-  DVSG_RUN(launch_conv1(prec, src, src_kind, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s, net->conv1.bias, ws.bufA, B,
-                        H, W, d.H1, d.W1, s));
+  DVSG_RUN(launch_conv1(gprec == kF32X && g_x3_conv1 ? kF32X : prec, src, src_kind, net->conv1.wt, net->conv1.wt16, net->conv1.wt32s,
+                        net->conv1.wt3x, net->conv1.bias, ws.bufA, B, H, W, d.H1, d.W1, s));
   }
   DVSG_TAP(0, ws.bufA, d.H1, d.W1, 64);
   {
@@ -508,7 +538,10 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
     const int calib_slot = 3 * (stage - 2);
     DVSG_RUN(calib_record(calib_slot, X, (long)B * h * w, u.c1.cin, s));
     // (float16 mode: the fused kernel multiplies against the stacked hi / lo weights only)
-    const bool fuse23 = conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) &&
+    // (f32x3: block 1's fused kernel multiplies with float32 matrix instructions; its stride-1 unit without a shortcut and its
+    // stride-2 unit run faster as two f32x3 GEMMs -- g_x3_fuse: 0 never fused, 1 the opening unit only, 2 all three)
+    const bool x3_unfused = gprec == kF32X && (g_x3_fuse == 0 || (g_x3_fuse == 1 && !u.has_shortcut));
+    const bool fuse23 = !x3_unfused && conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) &&
                         (prec != kF16 || (f16_pairs(net, u.block, kKindC2) && f16_pairs(net, u.block, kKindC3) &&
                                           (!u.has_shortcut || f16_pairs(net, u.block, kKindSc))));
     // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
@@ -1011,6 +1044,14 @@ int dvsg_debug_set_option(const char *name, int value) {
   }
   if (std::strcmp(name, "concat_sc") == 0) {
     g_concat_sc = value != 0;
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "x3_conv1") == 0) {
+    g_x3_conv1 = value;
+    return DVSG_OK;
+  }
+  if (std::strcmp(name, "x3_fuse") == 0) {
+    g_x3_fuse = value;
     return DVSG_OK;
   }
   if (std::strcmp(name, "fuse_shortcut") == 0) {

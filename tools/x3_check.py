@@ -101,3 +101,20 @@ if "time" in what:
             times.setdefault(prec, []).append(e0.elapsed_time(e1) / 6)
     for prec, t in times.items():
         print("B=16 1280x720 %s: %.3f ms/step  %.1f frames/s" % (prec, statistics.median(t), 16e3 / statistics.median(t)), flush=True)
+
+if "conv1" in what:
+    # conv1 tap (stage 0) of the f32x3 kernel against the exact kernel and a float64 torch convolution of the scaled input
+    import numpy as np
+    import bench
+    from coupe.dvsg_amd.networks import LocNet
+    from coupe.dvsg_amd.weights import make_synthetic_weights
+    net = LocNet(make_synthetic_weights(0))
+    for B, H, W in [(2, 64, 96), (1, 70, 101), (2, 288, 512), (1, 720, 1280), (1, 7, 5)]:
+        x = bench.gpu_windows(B, H, W, 77, dev)
+        a32 = net.tap(x, 0, precision="f32")
+        a3 = net.tap(x, 0, precision="f32x3")
+        _lib.call("dvsg_debug_set_option", b"x3_conv1", 0)
+        a3off = net.tap(x, 0, precision="f32x3")
+        _lib.call("dvsg_debug_set_option", b"x3_conv1", 1)
+        print("conv1 B=%d %dx%d: |x3 - f32| %.3g (max |y| %.3g), x3_conv1=0 equals f32: %s" % (
+            B, W, H, float((a3 - a32).abs().max()), float(a32.abs().max()), torch.equal(a3off, a32)), flush=True)
