@@ -36,6 +36,10 @@ def test_bench_line_has_the_contract_fields():
     assert c["cpu_model"] and c["cnn_ms_per_frame"] > 0 and c["warp_ms_per_frame"] > 0
     s2 = d["secondary"]      # the f32s rate, beside the line of record and outside its timed region
     assert s2["precision"] == "f32s" and s2["dtype"] == "f32x2f16" and s2["value"] > 0
+    x3 = d["f32x3"]          # the f32x3 rate (products from three bfloat16 pieces per operand), with its own roofline and latency
+    assert "error" not in x3, x3
+    assert x3["precision"] == "f32x3" and x3["value"] > 0 and x3["roofline"]["peak"] == pytest.approx(2500.0 / 6.0)
+    assert 0 < x3["latency"]["1280x720"]["ms_per_frame"] < 2.4 and 0 < x3["latency"]["512x288"]["ms_per_frame"] < 1.25
     # the reference's own operating point -- eval.py's batch-1 autoregressive clip loop -- beside the line, with a bound
     # that catches a regression of the per-frame path: 1.25 x the measured values (MI355X, rounds 3 and 4: 2.14-2.15 ms at
     # 720p, 1.10-1.11 ms at 512x288)
@@ -73,6 +77,12 @@ def test_bench_f32s_precision_is_separately_named():
     d = _run("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "96", "--width", "160", "--precision", "f32s",
              "--no-cpu-baseline")
     assert d["dtype"] == "f32x2f16" and "secondary" not in d and d["roofline"]["peak"] == pytest.approx(2500.0 / 3.0)
+
+
+def test_bench_f32x3_precision_is_separately_named():
+    d = _run("--steps", "2", "--warmup", "1", "--batch", "2", "--height", "96", "--width", "160", "--precision", "f32x3",
+             "--no-cpu-baseline")
+    assert d["dtype"] == "f32x3bf16" and "f32x3" not in d and d["roofline"]["peak"] == pytest.approx(2500.0 / 6.0)
 
 
 def test_bench_tf_warp_workload():

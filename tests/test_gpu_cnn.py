@@ -236,7 +236,7 @@ def test_ragged_and_extreme_shapes(net, synthetic_weights, B, H, W):
     assert np.abs(F16 - F_ref).max() < 3e-3
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f32s", "f32x3"])
 def test_a_step_replays_from_a_captured_hip_graph(net, precision):
     """The library allocates and synchronises nothing inside a call: a dvsg_stabilize_* step can be
     captured into a HIP graph as it stands and replays bit for bit, split-K tickets included."""

@@ -66,7 +66,7 @@ def test_mask_plane_is_the_projective_warp_of_ones(B, H, W):
             assert (got == 0.0).any() or (got < 1.0).mean() > 0.05
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f32s", 2e-5), ("f16", 4e-3)])
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f32s", 2e-5), ("f32x3", 2e-5), ("f16", 4e-3)])
 @pytest.mark.parametrize("B,H,W", SHAPES)
 def test_masked_conv1_matches_the_oracle_and_the_sources_agree(net, synthetic_weights, precision, tol, B, H, W):
     """conv1 (+ fused mask and scale_RGB) from a masked window against the oracle's conv1 of `patches * mask`; a float
@@ -102,7 +102,7 @@ def test_masked_conv1_matches_the_oracle_and_the_sources_agree(net, synthetic_we
         assert torch.equal(w, r8), "%s stage %d uint8 ring: %g" % (precision, stage, float((w - r8).abs().max()))
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32s", "f32x3"])
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 53), (2, 30, 600)])
 def test_a_mask_of_ones_reproduces_the_unmasked_entry_points_bit_for_bit(net, precision, B, H, W):
     """(x * 1.0f) * 255 - mean == x * 255 - mean, and for uint8 frames float32(v / 255.) * 255 == float(v): the identity
@@ -221,7 +221,7 @@ def test_teacher_forced_clip_is_eval_train_py(synthetic_weights):
         stabilize_clip_teacher_forced(model, unstab, stab, mask_H=np.zeros((3, 8), np.float32))
 
 
-@pytest.mark.parametrize("precision,f_tol", [("f32", 1e-5), ("f32s", 1e-5), ("f16", 5e-5)])
+@pytest.mark.parametrize("precision,f_tol", [("f32", 1e-5), ("f32s", 1e-5), ("f32x3", 1e-5), ("f16", 5e-5)])
 def test_masked_graph_at_720p(synthetic_weights, precision, f_tol):
     """One 1280x720 window through the masked graph in each precision: F_t against the oracle (torch-CPU CNN on
     patches * mask), pixels < 1e-3 outside sampler A's counted border pixels."""

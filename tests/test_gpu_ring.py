@@ -44,7 +44,7 @@ def _pool_and_table(n, B, H, W, seed, dtype="f32"):
 SHAPES = [(2, 64, 96), (1, 37, 53), (3, 20, 4), (1, 8, 8), (1, 1, 1), (2, 30, 600), (1, 5, 301)]
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32s", "f32x3"])
 @pytest.mark.parametrize("B,H,W", SHAPES)
 def test_conv1_from_a_float_ring_is_the_gathered_window(net, precision, B, H, W):
     """conv1 (+ fused scale_RGB) and the max pool from the ring, against the same kernels on the gathered window."""
@@ -62,7 +62,7 @@ def test_conv1_from_a_float_ring_is_the_gathered_window(net, precision, B, H, W)
     assert torch.equal(net.forward_ring(pool, table, precision=precision), net.forward(x, precision=precision))
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16", "f32s"])
+@pytest.mark.parametrize("precision", ["f32", "f16", "f32s", "f32x3"])
 @pytest.mark.parametrize("B,H,W", SHAPES)
 def test_uint8_ring_is_the_float_ring_of_the_converted_frames(net, precision, B, H, W):
     """eval.py:80 (`frame / 255.`, float64, fed as float32) fused: float32(v / 255.) * 255 == v for every byte, so

@@ -14,7 +14,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-CLASSES = {"conv1_kernel": 0, "conv1_f16_kernel": 0, "conv1_f16_pair_kernel": 0, "conv1_f16_march_kernel": 0, "conv1_split_kernel": 0, "maxpool_p_kernel": 3, "maxpool_h8_kernel": 3, "avgpool_partial_p_kernel": 4, "conv_gemm": None, "maxpool_kernel": 3, "tps_solve_kernel": 5, "tps_warp_kernel": 6,
+CLASSES = {"conv1_kernel": 0, "conv1_x3_kernel": 0, "conv1_f16_kernel": 0, "conv1_f16_pair_kernel": 0, "conv1_f16_march_kernel": 0, "conv1_split_kernel": 0, "maxpool_p_kernel": 3, "maxpool_h8_kernel": 3, "avgpool_partial_p_kernel": 4, "conv_gemm": None, "maxpool_kernel": 3, "tps_solve_kernel": 5, "tps_warp_kernel": 6,
            "stn_kernel": 7, "flow_warp_strip_kernel": 7, "mask_plane_kernel": 7, "dense_kernel": 4, "avgpool_partial_kernel": 4, "dense_finalize_kernel": 4}
 
 
@@ -64,8 +64,13 @@ def kprec(name):
         base = s[m.end():m.end() + int(m.group(1))] if m else s
         if base == "conv1_split_kernel":
             return "f32s"
-        if base == "conv_gemm_kernel":
-            return "f16" if "IDF16_" in s else ("f32s" if s.split("EEv")[0].endswith("Lb1") else "f32")
+        if base == "conv1_x3_kernel":
+            return "f32x3"
+        if base == "conv_gemm_kernel":   # <T, BN, WM, WN, KS, RELU, RES, MODE, SPLIT, X3>
+            if "IDF16_" in s:
+                return "f16"
+            lb = re.findall(r"Lb([01])E", s.split("EEv")[0] + "E")
+            return "f32x3" if lb[-1:] == ["1"] else ("f32s" if lb[-2:-1] == ["1"] else "f32")
         return "f16" if "DF16_" in s else None
     if s.startswith(("conv_wide16", "conv3x3_1x1_f16_kernel", "conv1_f16_kernel", "maxpool_h8_kernel")) or "_Float16" in s:
         return "f16"
@@ -74,9 +79,11 @@ def kprec(name):
     m = re.match(r"conv3x3_1x1_kernel<\d+, (true|false)>", s)
     if m:
         return "f32s" if m.group(1) == "true" else "f32"
-    m = re.match(r"conv_gemm_kernel<float(?:, \w+)*, (true|false)>", s)
+    m = re.match(r"conv_gemm_kernel<float(?:, \w+)*, (true|false), (true|false)>", s)   # ..., SPLIT, X3>
     if m:
-        return "f32s" if m.group(1) == "true" else "f32"
+        return "f32x3" if m.group(2) == "true" else ("f32s" if m.group(1) == "true" else "f32")
+    if s.startswith("conv1_x3_kernel"):
+        return "f32x3"
     if s.startswith(("conv1_kernel", "maxpool_kernel<float>", "avgpool_partial_kernel<float>")):
         return "f32"
     return None
@@ -102,9 +109,11 @@ def counters(d):
 
 def write_pmc(d, path, precision, drop_foreign=False):
     per, disp, dur = counters(d)
-    foreign = sorted({short(k) for k in per if kclass(k) is not None and kprec(k) not in (None, precision)})
+    # (the f32x3 precision runs the pools, the head and block 1's opening unit on the float32 kernels themselves)
+    allowed = (None, precision, "f32") if precision == "f32x3" else (None, precision)
+    foreign = sorted({short(k) for k in per if kclass(k) is not None and kprec(k) not in allowed})
     if foreign and drop_foreign:    # bench.py --calibrate: ONE float32 pass over one window before the float16 run; left out
-        for k in [k for k in per if kclass(k) is not None and kprec(k) not in (None, precision)]:
+        for k in [k for k in per if kclass(k) is not None and kprec(k) not in allowed]:
             del per[k]
             del disp[k]
         foreign = []
