@@ -27,6 +27,11 @@ for arg in sys.argv[1:]:
         hi = wt.half()
         lo = (wt - hi.float()).half()
         wt = torch.cat([hi.reshape(cout, K // 32, 32), lo.reshape(cout, K // 32, 32)], 2).contiguous()
+    if os.environ.get("PROBE_PREC") == "f32x3":  # bfloat16 piece stages (dvsg_pack_weights_f32x3)
+        FN = "dvsg_conv_gemm_f32x3"
+        packed = torch.empty((cout * K * 6,), dtype=torch.uint8, device=dev)
+        _lib.call("dvsg_pack_weights_f32x3", wt.data_ptr(), packed.data_ptr(), cout, K, stream)
+        wt = packed
     scratch = torch.zeros(66 << 20, dtype=torch.uint8, device=dev)
     _lib.call("dvsg_debug_set_option", b"conv_variant", 6)   # no stream-K: every tile is a mode-0 workgroup
     REP = int(os.environ.get("PROBE_REP", "1"))     # back-to-back launches before the measured one (clock governor settles)
