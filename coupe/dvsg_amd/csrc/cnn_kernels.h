@@ -100,7 +100,11 @@ struct ConvFused {
   // float16 mode: x, res / sc_x, y are float16 tensors and wt2, wt3, sc_wt the layers' stacked [hi | lo] float16 matrices
   // ([cout/64][128][K], conv_gemm.hip SPLIT), passed through the float pointers
   int f16 = 0;
+  // "f32x3": x, res, y are float32 tensors as in the float32 form; wt2, wt3 are the layers' packed bfloat16 piece stages
+  // (launch_pack_x3), passed through the float pointers; the residual is a tensor (no fused shortcut): conv_fused_x3.hip
+  int x3 = 0;
 };
+int launch_conv3x3_1x1_x3(const ConvFused &p, hipStream_t s);
 bool conv_fusable(int prec, int Cin, int Cmid, int Cout, int ksize);
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s);
 void set_fuse_conv(int v);

@@ -952,6 +952,7 @@ static int launch_conv3x3_1x1_f16(const ConvFused &p, hipStream_t s) {
 
 int launch_conv3x3_1x1(const ConvFused &p, hipStream_t s) {
   if (p.f16) return launch_conv3x3_1x1_f16(p, s);
+  if (p.x3) return launch_conv3x3_1x1_x3(p, s);
   DVSG_REQUIRE(p.Cin % 32 == 0 && p.Cin >= 64 && p.Cout % 128 == 0, "conv3x3_1x1: Cin=%d must be a multiple of 32 (>= 64), Cout=%d of 128",
                p.Cin, p.Cout);
   const bool sc = p.sc_x != nullptr;  // the residual is the 1x1 shortcut conv of sc_x, computed in the kernel

@@ -335,7 +335,7 @@ inline bool f16_pairs(const dvsg_locnet *net, int block, int kind) {
 // block 1's shortcut conv inside the fused conv2 + conv3 kernel (dvsg_debug_set_option("fuse_shortcut", 0): A/B)
 int g_fuse_shortcut = 1;
 int g_x3_conv1 = 1;  // dvsg_debug_set_option("x3_conv1", 0): the f32x3 precision with the float32 conv1 kernel (A/B)
-int g_x3_fuse = 1;   // dvsg_debug_set_option("x3_fuse", v): A/B of block 1's fusion in the f32x3 precision (forward())
+int g_x3_fuse = 3;   // dvsg_debug_set_option("x3_fuse", v): A/B of block 1's fusion in the f32x3 precision (forward())
 // blocks 2-4's opening units: shortcut + conv1 as one launch (dvsg_debug_set_option("concat_sc", 0): A/B)
 int g_concat_sc = 1;
 
@@ -538,14 +538,16 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
     const int calib_slot = 3 * (stage - 2);
     DVSG_RUN(calib_record(calib_slot, X, (long)B * h * w, u.c1.cin, s));
     // (float16 mode: the fused kernel multiplies against the stacked hi / lo weights only)
-    // (f32x3: block 1's fused kernel multiplies with float32 matrix instructions; its stride-1 unit without a shortcut and its
-    // stride-2 unit run faster as two f32x3 GEMMs -- g_x3_fuse: 0 never fused, 1 the opening unit only, 2 all three)
+    // (f32x3: block 1's units run conv2 + conv3 in the f32x3 fused kernel, conv_fused_x3.hip, the opening unit's shortcut as
+    // its own f32x3 GEMM -- g_x3_fuse = 3; A/B: 0 never fused, 1 the opening unit only and in the exact float32 kernel with
+    // its shortcut, 2 all three in the exact float32 kernel)
+    const bool x3_fused = gprec == kF32X && g_x3_fuse == 3;
     const bool x3_unfused = gprec == kF32X && (g_x3_fuse == 0 || (g_x3_fuse == 1 && !u.has_shortcut));
     const bool fuse23 = !x3_unfused && conv_fusable(prec, u.c2.cin, u.c2.cout, u.c3.cout, u.c2.ksize) &&
                         (prec != kF16 || (f16_pairs(net, u.block, kKindC2) && f16_pairs(net, u.block, kKindC3) &&
                                           (!u.has_shortcut || f16_pairs(net, u.block, kKindSc))));
     // block 1's opening unit: its shortcut conv (64 -> 256) runs inside the fused conv2 + conv3 kernel
-    const bool fuse_sc = fuse23 && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
+    const bool fuse_sc = fuse23 && !x3_fused && u.has_shortcut && u.stride == 1 && u.shortcut.cin == 64 && u.shortcut.cout == 256 &&
                          g_fuse_shortcut;
     // blocks 2-4's opening units, float32 / f32s: shortcut and conv1 as ONE launch over [shortcut | conv1] weight rows; its
     // output [M, depth + base] sits in bufS, the shortcut in columns [0, depth) (conv3's residual, row stride depth + base),
@@ -574,10 +576,12 @@ int forward(const dvsg_locnet *net, int prec, const Conv1Src &src, int src_kind,
       ConvFused f;
       const bool pcs = prec == kF32S;
       auto wts_of = [&](const ConvLayer &L) {
+        if (x3_fused) return reinterpret_cast<const float *>(L.wt3x);
         return pcs ? reinterpret_cast<const float *>(L.wt32s) : prec == kF16 ? reinterpret_cast<const float *>(L.wt16s) : L.wt;
       };
       f.pieces = pcs;
       f.f16 = prec == kF16;
+      f.x3 = x3_fused;
       f.x = reinterpret_cast<const float *>(ws.r1); f.wt2 = wts_of(u.c2); f.bias2 = u.c2.bias; f.wt3 = wts_of(u.c3); f.bias3 = u.c3.bias;
       f.res = static_cast<const float *>(res); f.y = reinterpret_cast<float *>(Y);
       f.B = B; f.H = h; f.W = w; f.Cin = u.c2.cin; f.Ho = ho; f.Wo = wo; f.Cout = u.c3.cout;

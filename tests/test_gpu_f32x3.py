@@ -150,11 +150,16 @@ def test_f_t_against_the_float64_arbiter(net, synthetic_weights):
     for precision in ("f32", "f32x3"):
         F = net.forward(xt, precision=precision).cpu().numpy()
         pool = net.tap(xt, 18, precision=precision).cpu().numpy().reshape(rpool.shape)
-        errs[precision] = (np.abs(F - rF).max(), np.abs(pool - rpool).max() / np.abs(rpool).max())
+        e = (pool - rpool) / np.abs(rpool).max()
+        errs[precision] = (np.abs(F - rF).max(), np.sqrt((e ** 2).mean()), abs(e.mean()), np.abs(e).max())
         assert np.array_equal(F, net.forward(xt, precision=precision).cpu().numpy())
-    print("288x512 vs float64: F_t f32 %.3g f32x3 %.3g; pool5 (relative) f32 %.3g f32x3 %.3g"
-          % (errs["f32"][0], errs["f32x3"][0], errs["f32"][1], errs["f32x3"][1]))
-    assert errs["f32x3"][0] <= 1.25 * errs["f32"][0] + 2e-9 and errs["f32x3"][1] <= 1.25 * errs["f32"][1] + 1e-8
+    print("288x512 vs float64: F_t f32 %.3g f32x3 %.3g; pool5 (relative) rms f32 %.3g f32x3 %.3g, |mean| f32 %.3g f32x3 %.3g"
+          % (errs["f32"][0], errs["f32x3"][0], errs["f32"][1], errs["f32x3"][1], errs["f32"][2], errs["f32x3"][2]))
+    # the 4096 pooled features give stable statistics (rms, and the MEAN: a bias is what an average pool keeps -- one shared
+    # accumulator for all six cross terms showed up here as 4 x the exact path's mean error); F_t's maximum over 100 values of
+    # ~2e-8 moves by +-40 % between roundings
+    assert errs["f32x3"][1] <= 1.1 * errs["f32"][1] + 2e-9 and errs["f32x3"][2] <= 1.25 * errs["f32"][2] + 3e-9
+    assert errs["f32x3"][3] <= 1.5 * errs["f32"][3] + 1e-8 and errs["f32x3"][0] <= 2.0 * errs["f32"][0] + 5e-9
 
 
 def test_stabilize_720p_end_to_end(synthetic_weights):
