@@ -1632,32 +1632,42 @@ void conv1_x3_kernel(const Conv1Src src, const unsigned short *__restrict__ wt1x
     // word index of the lane's first tap pair: (42 pixel + 80 (st & 1) + 8 h) / 2
     const int a0 = kConv1Cin * (wave * 32 + r) + 40 * (st & 1) + 4 * h;
     const __bf16 *b0 = reinterpret_cast<const __bf16 *>(w_s) + r * kConv1X3Ld + 8 * h;
+    // software-pipelined: the activation fragments of step t + 1 (4-byte-aligned reads, the slow ones) are requested before the
+    // MFMAs of step t are issued; the weight fragments of a step are read when it starts (holding two steps of them as well
+    // spills the ring and masked sources' staging registers)
     struct Frag {
       union {
         unsigned u[4];
         bf16x8 v;
       } a[3];
-      bf16x8 bw[3][2];
     };
-    auto read_frag = [&](Frag &f, int t) __attribute__((always_inline)) {
+    auto read_a = [&](Frag &f, int t) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) f.a[p].u[j] = in_p[p][a0 + 8 * t + j];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          f.bw[p][ni] = *reinterpret_cast<const bf16x8 *>(b0 + (p * 64 + ni * 32) * kConv1X3Ld + 16 * t);
-      }
     };
-    Frag fr[2];
-    read_frag(fr[0], 0);
+    // (the ring and masked sources hold more staging registers: one set of fragments there, or the kernel spills)
+    constexpr bool PIPE = SRC < 2;
+    Frag fr[PIPE ? 2 : 1];
+    if (PIPE) read_a(fr[0], 0);
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
-      if (t + 1 < 5) read_frag(fr[(t + 1) & 1], t + 1);
+      bf16x8 bw[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          bw[p][ni] = *reinterpret_cast<const bf16x8 *>(b0 + (p * 64 + ni * 32) * kConv1X3Ld + 16 * t);
+      if (PIPE) {
+        if (t + 1 < 5) read_a(fr[(t + 1) & 1], t + 1);
+      } else {
+        read_a(fr[0], t);
+      }
       __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that do not need them
-      const Frag &f = fr[t & 1];
+      const Frag &f = fr[PIPE ? (t & 1) : 0];
 #define DVSG_C1X_TERM(C, PA, PB) \
-  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) C[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA].v, f.bw[PB][ni], C[ni], 0, 0, 0)
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) C[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[PA].v, bw[PB][ni], C[ni], 0, 0, 0)
       DVSG_C1X_TERM(accs, 2, 0);
       DVSG_C1X_TERM(accs, 0, 2);
       DVSG_C1X_TERM(accs, 1, 1);
