@@ -9,8 +9,9 @@
 // Four waves per workgroup (the f32x3 GEMM's reason: an activation fragment is split in registers, ~42 VALU that the
 // matrix pipe does not hide, so a wave's tile is wide along N -- one split serves 2 weight blocks in phase 1, 4 in phase 2).
 //   phase 1  conv2 tile 128 pixels x 64 channels, K = 9 Cin: conv_gemm_kernel<float, 64, 4, 1, 3, ..., X3>'s loop -- float32
-//            activation rows by LDS-DMA (XOR-swizzled, 2 x 16 KB at 0), packed weight piece stages (2 x 12 KB at 32 KB), channel
-//            chunk outer / taps inner; wave w owns pixels [32 w, 32 w + 32) x all 64 channels.
+//            activation rows by LDS-DMA (XOR-swizzled) through a ring of three 16 KB slots, two stages ahead; packed weight piece
+//            stages (2 x 12 KB behind them), one ahead; channel chunk outer / taps inner; wave w owns pixels [32 w, 32 w + 32) x
+//            all 64 channels.
 //   hand-over  bias + ReLU, the tile goes to LDS as float32 in the layout a staged activation stage has (two 32-k stages at 0).
 //   phase 2  the wave's four activation fragments (32 pixels x 64 mid channels) are read back and split ONCE -- 48 registers
 //            of pieces that serve every output channel; then per 64 output channels: conv3's packed piece stages (24 KB,
@@ -102,7 +103,8 @@ void conv3x3_1x1_x3_kernel(FusedX3Dev p) {
   // memory round trip, so with two stages in flight phase 1 waits for its loads, and phase 2 waits once per 64 channels for
   // the residual rows it asked for a group's MFMAs earlier; 2.7 TB/s of HBM, 0.5 of the matrix time.  Starting the second
   // workgroup of every CU a phase late -- so that one workgroup's loads would run under the other's MFMAs -- changed
-  // nothing (+-0.3 % of the step for 8 k ... 49 k cycles of delay); a third LDS stage does not fit 80 KB by 4 KB.)
+  // nothing (+-0.3 % of the step for 8 k ... 49 k cycles of delay).  What the numbers above led to: the three-slot activation
+  // ring of phase 1 below.)
 
   // ---------------------------------------------------------------- phase 1: conv2 tile 128 x 64
   long a_off[AG];
@@ -129,40 +131,53 @@ void conv3x3_1x1_x3_kernel(FusedX3Dev p) {
     }
     a_mask[i] = mk;
   }
-  int s_kh = 0, s_kw = 0, s_c0 = 0;
-  auto issue_stage = [&](int buf) __attribute__((always_inline)) {
-    const float *xa = p.x + ((long)s_kh * p.W + s_kw) * p.Cin + s_c0;
-    const int wk = (s_kh * 3 + s_kw) * p.Cin + s_c0;
+  // The activation stages (HBM, the long round trip) go through a ring of THREE 16 KB slots, two stages ahead of the one being
+  // multiplied; the weight piece stages (12 KB, L2-resident) through two, one ahead: 72 KB.  A stage is 0.6 us of work per wave
+  // in this arithmetic, less than a memory round trip: with one stage of lead the loop waited for its loads.  Issue order per
+  // iteration: weights of stage kt + 1, then activations of stage kt + 2 -- LDS-DMA lands in issue order, so "at most the
+  // youngest AG instructions outstanding" means stage kt + 1 is complete while stage kt + 2 stays in flight across the barrier.
+  char *Ws2 = lds + 3 * A_STAGE;
+  int a_kh = 0, a_kw = 0, a_c0 = 0;
+  auto issue_a = [&](int slot) __attribute__((always_inline)) {
+    const float *xa = p.x + ((long)a_kh * p.W + a_kw) * p.Cin + a_c0;
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
-      const bool ok = ((a_mask[i] >> s_kh) & (a_mask[i] >> (4 + s_kw)) & 1u) != 0;
+      const bool ok = ((a_mask[i] >> a_kh) & (a_mask[i] >> (4 + a_kw)) & 1u) != 0;
       const void *src = ok ? static_cast<const void *>(xa + a_off[i]) : static_cast<const void *>(&g_zero16x);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (slot * BM + 8 * (wave + NW * i)) * ROWB), 16, 0, 0);
     }
-    // the stage's 12 KB of weight pieces, linearly: 1 KB runs wave, wave + 4, wave + 8
+    if (++a_kw == 3) {
+      a_kw = 0;
+      if (++a_kh == 3) {
+        a_kh = 0;
+        a_c0 += 32;
+      }
+    }
+  };
+  // K order: channel chunk outer, the 9 taps inner (conv_gemm_tile.h); the weight stage of (tap, c0) is stage (tap Cin + c0) / 32
+  // of the packed matrix.  12 KB, linearly: 1 KB runs wave, wave + 4, wave + 8
+  int w_tap = 0, w_c0 = 0;
+  auto issue_w = [&](int buf) __attribute__((always_inline)) {
+    const int wk = w_tap * p.Cin + w_c0;
     const char *wsrc = reinterpret_cast<const char *>(p.wt2x) + (size_t)(wk >> 5) * W2_STAGE + lane * 16;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (wave + NW * i) * 1024),
-                                       (lptr_t)(Ws + buf * W2_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
-    if (++s_kw == 3) {
-      s_kw = 0;
-      if (++s_kh == 3) {
-        s_kh = 0;
-        s_c0 += 32;
-      }
+                                       (lptr_t)(Ws2 + buf * W2_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
+    if (++w_tap == 9) {
+      w_tap = 0;
+      w_c0 += 32;
     }
   };
-  constexpr int PER = AG + 3;   // LDS-DMA instructions per wave and stage
 
   floatx16 acc1[2], acc1s[2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc1[ni][q] = acc1s[ni][q] = 0.f;
-  auto compute_stage = [&](int buf) __attribute__((always_inline)) {
-    const char *a_row = As + (buf * BM + wave * 32 + r) * ROWB;
-    const char *b_row = Ws + buf * W2_STAGE + r * 64;
+  auto compute_stage = [&](int slot, int buf) __attribute__((always_inline)) {
+    const char *a_row = As + (slot * BM + wave * 32 + r) * ROWB;
+    const char *b_row = Ws2 + buf * W2_STAGE + r * 64;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int g = 2 * t + h;
@@ -174,23 +189,26 @@ void conv3x3_1x1_x3_kernel(FusedX3Dev p) {
     }
   };
 
-  issue_stage(0);
-  issue_stage(1);  // KT >= 18
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  issue_a(0);
+  issue_w(0);
+  issue_a(1);   // KT >= 18
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AG) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  compute_stage(0);
-  __builtin_amdgcn_sched_barrier(0);
-  for (int kt = 1; kt < KT - 1; ++kt) {
-    __syncthreads();
-    issue_stage((kt + 1) & 1);
+  int slot = 0, slot2 = 2;   // ring slots of stages kt and kt + 2
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) issue_w((kt + 1) & 1);
+    if (kt + 2 < KT) issue_a(slot2);
     __builtin_amdgcn_sched_barrier(0);
-    compute_stage(kt & 1);
+    compute_stage(slot, kt & 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    slot = slot == 2 ? 0 : slot + 1;
+    slot2 = slot2 == 2 ? 0 : slot2 + 1;
   }
-  __syncthreads();
-  compute_stage((KT - 1) & 1);
 
   // conv3's weight pieces of output channels [64 q, 64 q + 64): the group's two 32-k stages are 24 KB in a row in the packed
   // matrix, 24 runs of 1 KB over the four waves, into weight buffer q & 1
