@@ -253,20 +253,22 @@ int dvsg_pieces_to_f32(const void *x, float *y, size_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * "f32x3": float32 tensors everywhere -- boundary, workspace, every activation between the layers, exactly as the *_f32
- * entry points -- and float32 accumulation; inside the 52 1x1 / 3x3 convolutions every PRODUCT is formed on the bfloat16
+ * entry points -- and float32 accumulation; inside conv1 and the 52 1x1 / 3x3 convolutions every PRODUCT is formed on the bfloat16
  * matrix cores from THREE bfloat16 pieces per operand, x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1),
  * x3 = bf16(x - x1 - x2) (round to nearest).  bfloat16 has float32's exponent range and 8 significant bits, so the three
  * pieces hold all 24 significant bits of ANY finite float32 operand above 2^-110 -- no magnitude condition, unlike the two
  * float16 pieces of "f32s" -- and each piece product is exact in float32.  Of the nine cross terms of a w the six largest
  * (a1 w1, a1 w2, a2 w1, a2 w2, a1 w3, a3 w1) are accumulated, six v_mfma_f32_32x32x16_bf16 where the exact path issues
  * eight v_mfma_f32_32x32x2_f32 at 2.7 x the matrix-core time; the dropped a2 w3 + a3 w2 + a3 w3 are bounded by 2^-23 |a w|
- * -- one rounding of a float32 multiply; 2^-27 typically -- and each MFMA rounds its 16-term sum into the float32
- * accumulator once, so a K-long dot product sees 6 K / 16 accumulator roundings where the float32 FMA chain sees K.
- * Activations are split in registers behind the LDS fragment read; weights once at load (dvsg_locnet_create;
- * dvsg_pack_weights_f32x3 for a single layer).  conv1, the pools, block 1's fused conv2 + conv3, the dense head, the TPS
- * solve and the warp are the float32 kernels themselves.  Measured against a float64 evaluation it is as close as the
- * exact path is (tests/test_gpu_f32x3.py).  A separately named precision: dvsg_*_f32 stays the path whose matrix
- * instructions are float32 ones.
+ * -- one rounding of a float32 multiply; 2^-27 typically.  The large term a1 w1 and the five small ones accumulate in
+ * SEPARATE float32 accumulators, joined once per tile: an MFMA adds its 16 products to the accumulator with the bits below the
+ * accumulator's last place cut off, a bias that a shared accumulator lets through the network's average pool.
+ * Activations are split in registers behind the LDS fragment read (conv1: once while its input row is staged; block 1's
+ * fused conv2 + conv3: conv3's operand once per tile); weights once at load (dvsg_locnet_create; dvsg_pack_weights_f32x3 for
+ * a single layer).  The pools, the dense head, the TPS solve and the warp are the float32 kernels themselves.  Measured
+ * against float64 evaluations it is as close as the exact path is, layer by layer and end to end (tests/test_gpu_f32x3.py,
+ * tests/test_f32x3_numerics_cpu.py); bitwise reproducible.  A separately named precision: dvsg_*_f32 stays the path whose
+ * matrix instructions are float32 ones.
  * ------------------------------------------------------------------------------------- */
 int dvsg_locnet_forward_f32x3(const dvsg_locnet_t *net, const float *patches, int B, int H, int W,
                               float *F_t, void *workspace, size_t workspace_bytes, void *stream);
