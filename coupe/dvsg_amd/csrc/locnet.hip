@@ -404,6 +404,8 @@ int run_conv(int prec, const ConvLayer &L, bool pairs, const void *x, int B, int
   p.prec = prec == kF32S || prec == kF32X ? kF32 : prec;
   p.wsplit = prec == kF32S || (prec == kF16 && pairs);
   p.x3 = prec == kF32X;
+  if (prec == kF32X && !L.wt3x)
+    return fail(DVSG_ERR_UNSUPPORTED, "f32x3: layer %d -> %d (k = %d) has no packed bfloat16 pieces (K %% 32, Cout %% 64)", L.cin, L.cout, L.ksize);
   p.x = x; p.wt = L.weights(prec, p.wsplit != 0); p.bias = L.bias; p.res = res; p.y = y;
   if (prec == kF16 && pairs) {
     p.wt_packed = L.wt16p;
