@@ -49,6 +49,7 @@ SIGNATURES = {
     "dvsg_stabilize_f32x3": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_conv_gemm_f32x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp],
     "dvsg_pack_weights_f32x3": [_vp, _vp, _i, _i, _vp],
+    "dvsg_conv3x3_1x1_f32x3": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "dvsg_f32_to_pieces": [_vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_pieces_to_f32": [_vp, _vp, ctypes.c_size_t, _vp],
     "dvsg_locnet_forward_f16": [_vp, _vp, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp],

@@ -1002,6 +1002,23 @@ int dvsg_conv3x3_1x1_f32(const float *x, const float *wt2, const float *bias2, c
   return launch_conv3x3_1x1(f, as_stream(stream));
 }
 
+int dvsg_conv3x3_1x1_f32x3(const float *x, const void *wt2_packed, const float *bias2, const void *wt3_packed, const float *bias3,
+                           const float *res, float *y, int B, int H, int W, int Cin, int Cout, int stride, int res_stride,
+                           void *stream) {
+  DVSG_REQUIRE(x && wt2_packed && bias2 && wt3_packed && bias3 && res && y, "dvsg_conv3x3_1x1_f32x3: NULL pointer");
+  DVSG_REQUIRE(B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && res_stride >= 1,
+               "dvsg_conv3x3_1x1_f32x3: bad shape B=%d H=%d W=%d stride=%d res_stride=%d", B, H, W, stride, res_stride);
+  ConvFused f;
+  f.x = x; f.wt2 = static_cast<const float *>(wt2_packed); f.bias2 = bias2; f.wt3 = static_cast<const float *>(wt3_packed);
+  f.bias3 = bias3; f.res = res; f.y = y;
+  f.B = B; f.H = H; f.W = W; f.Cin = Cin; f.Cout = Cout;
+  f.Ho = (H - 1) / stride + 1; f.Wo = (W - 1) / stride + 1;
+  f.stride = stride;
+  f.res_H = (f.Ho - 1) * res_stride + 1; f.res_W = (f.Wo - 1) * res_stride + 1; f.res_stride = res_stride;
+  f.x3 = 1;
+  return launch_conv3x3_1x1(f, as_stream(stream));
+}
+
 int dvsg_debug_set_option(const char *name, int value) {
   DVSG_REQUIRE(name, "dvsg_debug_set_option: NULL name");
   if (std::strcmp(name, "conv_variant") == 0) {

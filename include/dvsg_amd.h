@@ -286,6 +286,12 @@ int dvsg_conv_gemm_f32x3(const float *x, const void *wt_packed, const float *bia
                          float *y, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
                          int relu, int res_stride, void *scratch, size_t scratch_bytes, void *stream);
 int dvsg_pack_weights_f32x3(const float *wt, void *wt_packed, int Cout, int K, void *stream);
+/* dvsg_conv3x3_1x1_f32 (below) in that precision: conv2 (3x3, Cin -> 64, + bias + ReLU) and conv3 (1x1, 64 -> Cout, + bias +
+ * residual + ReLU) of a block-1 unit in one kernel, float32 tensors; wt2_packed / wt3_packed are dvsg_pack_weights_f32x3 of the
+ * float32 matrices [64][9 Cin] and [Cout][64].  Cin % 32 == 0 (>= 64), Cout % 64 == 0. */
+int dvsg_conv3x3_1x1_f32x3(const float *x, const void *wt2_packed, const float *bias2, const void *wt3_packed,
+                           const float *bias3, const float *res, float *y, int B, int H, int W, int Cin, int Cout,
+                           int stride, int res_stride, void *stream);
 
 /* x, wt, res, y are float16 (Cin % 64 == 0); bias float32. */
 int dvsg_conv_gemm_f16(const void *x, const void *wt, const float *bias, const void *res, void *y,

@@ -137,6 +137,54 @@ def test_layers_against_float64(k, stride, cin, cout, h, w, B, ascale, wscale):
     assert e3 <= 1.25 * e32 + 6e-8 * scale and r3 <= 1.1 * r32 + 1e-9 * scale
 
 
+@pytest.mark.parametrize("B,h,w,cin,cout,stride,res_stride", [(2, 45, 80, 64, 256, 1, 1), (1, 37, 53, 64, 256, 2, 2), (3, 20, 31, 128, 128, 1, 1),
+                                                             (1, 90, 160, 64, 256, 2, 1), (16, 180, 320, 64, 256, 1, 1), (1, 1, 1, 64, 64, 1, 1)])
+def test_fused_conv3x3_conv1x1_against_float64(B, h, w, cin, cout, stride, res_stride):
+    """Block 1's conv2 + conv3 in the precision's own fused kernel (conv_fused_x3.hip) against float64 math on the same
+    float32 operands, next to the exact fused kernel's error: ragged M tiles, stride 2 with the subsampled-shortcut residual,
+    other channel counts, a one-pixel frame, the full-size launch; the same bits on a second launch."""
+    import torch
+    from coupe.dvsg_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(17)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.rand((B, h, w, cin), generator=g, device=dev) - 0.3
+    w2 = (torch.rand((64, 9 * cin), generator=g, device=dev) - 0.5) * (2.0 / (9 * cin) ** 0.5)
+    b2 = torch.rand((64,), generator=g, device=dev) - 0.5
+    w3 = (torch.rand((cout, 64), generator=g, device=dev) - 0.5) * 0.25
+    b3 = torch.rand((cout,), generator=g, device=dev) - 0.5
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    res = torch.rand((B, (ho - 1) * res_stride + 1, (wo - 1) * res_stride + 1, cout), generator=g, device=dev) - 0.5
+    p2 = torch.empty((64 * 9 * cin * 6,), dtype=torch.uint8, device=dev)
+    p3 = torch.empty((cout * 64 * 6,), dtype=torch.uint8, device=dev)
+    _lib.call("dvsg_pack_weights_f32x3", w2.data_ptr(), p2.data_ptr(), 64, 9 * cin, st)
+    _lib.call("dvsg_pack_weights_f32x3", w3.data_ptr(), p3.data_ptr(), cout, 64, st)
+    ys = [torch.full((B, ho, wo, cout), float("nan"), device=dev) for _ in range(3)]
+    for y in ys[:2]:
+        _lib.call("dvsg_conv3x3_1x1_f32x3", x.data_ptr(), p2.data_ptr(), b2.data_ptr(), p3.data_ptr(), b3.data_ptr(), res.data_ptr(),
+                  y.data_ptr(), B, h, w, cin, cout, stride, res_stride, st)
+    exact_ok = cout % 128 == 0      # the exact fused kernel wants whole 128-channel halves
+    if exact_ok:
+        _lib.call("dvsg_conv3x3_1x1_f32", x.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), res.data_ptr(),
+                  ys[2].data_ptr(), B, h, w, cin, cout, stride, res_stride, st)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1]) and bool(torch.isfinite(ys[0]).all())
+    w2c = w2.double().reshape(64, 3, 3, cin).permute(0, 3, 1, 2)
+    mid = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w2c, b2.double(), stride=stride, padding=1))
+    ref = torch.nn.functional.conv2d(mid, w3.double().reshape(cout, 64, 1, 1), b3.double()).permute(0, 2, 3, 1)
+    ref = torch.relu(ref + res.double()[:, ::res_stride, ::res_stride])
+    scale = max(float(ref.abs().max()), 1.0)
+    e3 = float((ys[0].double() - ref).abs().max())
+    assert e3 <= 2e-6 * scale, e3 / scale
+    if exact_ok:
+        e32 = float((ys[2].double() - ref).abs().max())
+        print("fused %d->64->%d s%d B=%d: max err f32 %.2e f32x3 %.2e (of %.3g)" % (cin, cout, stride, B, e32 / scale, e3 / scale, scale))
+        assert e3 <= 1.25 * e32 + 6e-8 * scale
+    with pytest.raises(_lib.DvsgError):     # Cout % 64
+        _lib.call("dvsg_conv3x3_1x1_f32x3", x.data_ptr(), p2.data_ptr(), b2.data_ptr(), p3.data_ptr(), b3.data_ptr(), res.data_ptr(),
+                  ys[0].data_ptr(), B, h, w, cin, 96, stride, res_stride, st)
+
+
 def test_f_t_against_the_float64_arbiter(net, synthetic_weights):
     """The whole CNN at 288x512 against the float64 evaluation of the same graph on the same float32 weights and frames:
     the mode's F_t and pooled features are at most as far from it as the exact float32 path's (x 1.25)."""
