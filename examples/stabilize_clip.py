@@ -3,7 +3,7 @@
 reference's call surface.  The reference reads an .avi with cv2 and loads an .npz checkpoint; neither
 ships here, so this example uses a seeded synthetic clip and the seeded synthetic checkpoint.
 
-    python examples/stabilize_clip.py [--frames 8] [--height 288] [--width 512] [--ckpt DIR]
+    python examples/stabilize_clip.py [--frames 8] [--height 288] [--width 512] [--ckpt DIR] [--precision f32|f32x3|f32s|f16]
 """
 import argparse
 import os
@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--height", type=int, default=288)   # config.py:12-13
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--ckpt", default=None, help="reference checkpoint directory (with its `checkpoints` index)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3", "f32s", "f16"],
+                    help="f32: float32 matrix instructions (the default); f32x3: float32 tensors and float32-level results from "
+                         "three bfloat16 pieces per operand, ~1.3x faster (include/dvsg_amd.h)")
     args = ap.parse_args()
     import inputs
     # stands in for the decoded video: BGR uint8 frames of another size (eval.py:76-81 resizes them)
@@ -35,6 +38,7 @@ def main():
 
     sess = Session()                                              # eval.py:46  tf.Session(...)
     net = StabNet(args.height, args.width)                        # eval.py:50
+    net.precision = args.precision
     inputs_, outputs = net.get_evaluation_model(7)
     if args.ckpt:
         net.load_ckpt(args.ckpt, by_score=True)                   # eval.py:56  ckpt_manager.load_ckpt
